@@ -1,0 +1,140 @@
+/*
+ * tcgnn.h - C ABI of the MI355X-native TC-GNN aggregation engine (libtcgnn_hip.so).
+ *
+ * This is the drop-in boundary of the hot path.  Every entry point replaces one function of the
+ * reference's `TCGNN` pybind11 module (file:line relative to the reference checkout) and takes
+ * plain pointers and sizes only - no torch types.  A Python (ctypes), C++ or any FFI caller can
+ * bind it; the binding the reference's maintainers would add is shown in INTEGRATION.md.
+ *
+ *   reference (TCGNN_conv/TCGNN.cpp)                     this ABI
+ *   ---------------------------------------------------  --------------------------------------
+ *   preprocess            :172-226 (+ :157-170)          tcgnn_preprocess
+ *   preprocess_gpu        :229-256 (unfinished there)    tcgnn_preprocess_gpu
+ *   forward  = spmm_forward       :63-86   -> TCGNN_kernel.cu:175-220, :336-454     tcgnn_spmm
+ *   forward_AGNN = spmm_forward_AGNN :93-118 -> TCGNN_kernel.cu:227-279, :459-578   tcgnn_spmm_val
+ *   forward_ef = sddmm_forward    :126-150 -> TCGNN_kernel.cu:286-327, :584-727     tcgnn_sddmm
+ *   backward / backward_ef :270-271 (aliases of forward / forward_ef)               same two calls
+ *
+ * Conventions
+ *   - Every function returns a tcgnn_status (0 = OK) and never aborts the process (the reference
+ *     printf()s and exit(-1)s on a launch error, TCGNN_kernel.cu:211-217).  tcgnn_last_error()
+ *     returns a thread-local human-readable message for the last non-OK status.
+ *   - Device pointers are BORROWED for the duration of the call (the plan borrows the five legacy
+ *     arrays for its lifetime, see tcgnn_plan_create); outputs are caller-allocated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All device
+ *     work is enqueued asynchronously on it; only tcgnn_plan_create / tcgnn_preprocess_gpu
+ *     synchronise (once, to size their outputs).
+ *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
+ *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
+ *     TCGNN_kernel.cu:420).
+ *   - Tile unit: blockPartition counts 16x8 TC blocks per 16-row window (config.h:4-5); the
+ *     kernels consume them four at a time as 16x32 MFMA operand tiles.
+ */
+#ifndef TCGNN_H
+#define TCGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCGNN_ABI_VERSION 1
+#define TCGNN_BLK_H 16 /* rows per row window          (config.h:4) */
+#define TCGNN_BLK_W 8  /* condensed columns per TC block (config.h:5) */
+
+typedef enum tcgnn_status {
+    TCGNN_OK = 0,
+    TCGNN_ERR_INVALID_ARG = 1, /* null pointer, negative size, unsupported tile shape ... */
+    TCGNN_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed             */
+    TCGNN_ERR_OOM = 3,         /* host or device allocation failed                       */
+    TCGNN_ERR_BAD_GRAPH = 4,   /* metadata inconsistent with the CSR (out-of-range ids)  */
+    TCGNN_ERR_WORKSPACE = 5    /* workspace pointer null or smaller than required        */
+} tcgnn_status;
+
+/* Opaque device-resident translation of one graph: the condensed 16x32 tile stream the kernels
+ * read (per tile: 32 source-row ids, a 16x32 adjacency bitmask, 16 edge offsets). */
+typedef struct tcgnn_plan tcgnn_plan;
+
+typedef struct tcgnn_plan_info {
+    int32_t num_nodes;       /* N */
+    int32_t num_windows;     /* ceil(N/16) as given by the caller's blockPartition length */
+    int64_t num_edges;       /* E = nnz of the CSR */
+    int64_t tc_blocks;       /* sum(blockPartition): 16x8 TC blocks (the reference's "TC_Blocks") */
+    int64_t wide_blocks;     /* 16x32 operand tiles actually streamed by the kernels */
+    int64_t plan_bytes;      /* device bytes owned by the plan */
+    int32_t canonical;       /* 1 if every CSR row is strictly increasing (scipy canonical form) */
+    int32_t waves_per_window;/* workgroup shape the launcher picked (1 or 4 wavefronts) */
+} tcgnn_plan_info;
+
+int tcgnn_abi_version(void);
+const char* tcgnn_status_string(int status);
+const char* tcgnn_last_error(void);
+
+/* ---- sparse-graph translation (SGT) ------------------------------------------------------- */
+
+/* Host SGT.  Replaces TCGNN.preprocess (TCGNN.cpp:172-226): fills, in place,
+ *   edgeToRow[e]      = row of CSR edge e,
+ *   edgeToColumn[e]   = rank of edgeList[e] among the sorted unique column ids of e's row window,
+ *   blockPartition[w] = ceil(#unique / blockSize_w), and 1 for a window without edges (what the
+ *                       reference's zero-length read yields, TCGNN.cpp:160),
+ * for w < bp_len only (the reference writes one slot past the end when N % blockSize_h == 0).
+ * *tc_blocks receives the count the reference prints as "TC_Blocks" (including that phantom
+ * window).  All pointers are HOST memory.  num_threads <= 0 means "all hardware threads".
+ * Rows need not be sorted and may hold duplicate columns. */
+int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_t num_nodes,
+                     int32_t blockSize_h, int32_t blockSize_w, int32_t* blockPartition,
+                     int64_t bp_len, int32_t* edgeToColumn, int32_t* edgeToRow,
+                     int64_t* tc_blocks, int32_t num_threads);
+
+/* Device SGT.  Same outputs as tcgnn_preprocess, all pointers DEVICE memory.  Finishes what the
+ * reference's preprocess_gpu / fill_window only sketch (TCGNN.cpp:229-256,
+ * TCGNN_kernel.cu:42-80).  Synchronises `stream` once to return *tc_blocks. */
+int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_nodePointer,
+                         int32_t num_nodes, int64_t num_edges, int32_t blockSize_h,
+                         int32_t blockSize_w, int32_t* d_blockPartition, int64_t bp_len,
+                         int32_t* d_edgeToColumn, int32_t* d_edgeToRow, int64_t* tc_blocks,
+                         void* stream);
+
+/* ---- plan: legacy metadata -> packed tile stream (device) --------------------------------- */
+
+/* Builds the packed tile stream on the device from the five legacy arrays every reference entry
+ * point receives (TCGNN.cpp:63-70).  The arrays are DEVICE pointers and stay borrowed by the
+ * plan until tcgnn_plan_destroy (the fallback kernels for non-canonical CSRs read them).
+ * Synchronises `stream` once. */
+int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
+                      const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
+                      const int32_t* d_edgeToRow, int32_t num_nodes, int64_t num_edges,
+                      int32_t num_windows, void* stream, tcgnn_plan** plan_out);
+int tcgnn_plan_destroy(tcgnn_plan* plan);
+int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
+
+/* Scratch bytes the three kernels need for feature width D (fp16 staging copy of X with one
+ * zero sentinel row, plus the scale words).  The caller owns the scratch; it must be 256-byte
+ * aligned device memory and may be reused across calls on the same stream. */
+size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/* Y[N,D] = A_bin * X.  Replaces TCGNN.forward / TCGNN.backward (TCGNN.cpp:63-86).
+ * X, Y: fp32 row-major device arrays [N, D]; Y is fully overwritten (rows without edges = 0).
+ * Operands are rounded to a 10-bit mantissa (fp16, per-call power-of-two scaled) exactly as the
+ * reference rounds to TF32; products accumulate in fp32 on MFMA. Any D >= 1. */
+int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D,
+               void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Y[N,D] = A_val * X with A_val[r,c] = d_edge_val[e] for CSR edge e = (r,c).
+ * Replaces TCGNN.forward_AGNN (TCGNN.cpp:93-118); d_edge_val is row 0 of edgeAttention[H,E]. */
+int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y,
+                   int32_t D, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ef[e] = <X[row(e),:], X[col(e),:]> for every CSR edge.  Replaces TCGNN.forward_ef /
+ * TCGNN.backward_ef (TCGNN.cpp:126-150).  d_ef: fp32 [E], fully overwritten. */
+int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D,
+                void* d_workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCGNN_H */

@@ -1,0 +1,267 @@
+"""`TCGNN` - drop-in replacement of the reference's PyTorch extension module of the same name.
+
+Same seven names, same positional signatures, same return shapes as the pybind11 module built from
+TCGNN_conv/TCGNN.cpp:260-272, so the reference's gnn_conv.py / main_tcgnn.py import and call it
+unchanged (`import TCGNN`):
+
+    preprocess(edgeList, nodePointer, num_nodes, blockSize_h, blockSize_w,
+               blockPartition, edgeToColumn, edgeToRow) -> None        TCGNN.cpp:172
+    preprocess_gpu(... same, CUDA tensors ...)              -> None        TCGNN.cpp:229
+    forward(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow) -> [Y]    :63
+    forward_ef(...same six...)                                                    -> [ef]   :126
+    forward_AGNN(input, nodePointer, edgeList, edgeAttention, blockPartition,
+                 edgeToColumn, edgeToRow)                                         -> [Y]    :93
+    backward = forward, backward_ef = forward_ef                                            :270-271
+
+Behind it sits the C ABI of include/tcgnn.h (libtcgnn_hip.so, hand-written gfx950 kernels).  Torch
+is only plumbing here: device memory, the current HIP stream, tensor lifetime.  There is no CPU or
+eager fallback; a missing library fails at import.
+
+Differences from the reference that a caller can observe (all supersets):
+  * any embedding_dim is computed in full (the reference leaves columns >= 16*min(D//16, 8) zero),
+  * launch errors raise RuntimeError instead of printf + exit(-1) (TCGNN_kernel.cu:211-217),
+  * kernels run on torch's current stream (the reference uses the legacy default stream and, for
+    forward_AGNN, a leaked stream per call, TCGNN_kernel.cu:245-255),
+  * preprocess never writes past the end of blockPartition when num_nodes % blockSize_h == 0.
+"""
+import collections
+import sys
+
+import torch
+
+import tcgnn_capi as _c
+
+__all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
+           "plan_info", "clear_plan_cache"]
+
+_PLAN_CACHE_SIZE = 8
+_plans = collections.OrderedDict()  # key -> (handle, tensors kept alive)
+_workspaces = {}                    # (device index, stream id) -> uint8 tensor
+
+
+# ---------------------------------------------------------------- argument checks (TCGNN.cpp:54-56)
+
+def _check_input(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _check_int(t, name):
+    if t.dtype != torch.int32:  # libtorch's data<int>() raises the same way in the reference
+        raise RuntimeError("expected scalar type Int but found %s (%s)" % (str(t.dtype).replace("torch.", "").capitalize(), name))
+
+
+def _check_float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float but found %s (%s)" % (str(t.dtype).replace("torch.", "").capitalize(), name))
+
+
+def _stream_handle(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ---------------------------------------------------------------- plan cache
+
+def _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """The packed tile stream is a pure function of the five metadata tensors; it is built on the
+    device the first time they are seen and reused while they are unchanged (storage address,
+    length and in-place version counter).  The cache keeps the tensors alive, so an address can not
+    be recycled under a live entry."""
+    tensors = (nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    key = tuple((t.data_ptr(), t.numel(), t._version) for t in tensors) + (nodePointer.device.index,)
+    hit = _plans.get(key)
+    if hit is not None:
+        _plans.move_to_end(key)
+        return hit[0]
+    dev = nodePointer.device
+    for t, n in zip(tensors, ("nodePointer", "edgeList", "blockPartition", "edgeToColumn", "edgeToRow")):
+        _check_int(t, n)
+        if t.device != dev:
+            raise RuntimeError("%s is on %s but nodePointer is on %s" % (n, t.device, dev))
+    N = nodePointer.numel() - 1
+    E = edgeList.numel()
+    if N < 0:
+        raise RuntimeError("nodePointer must hold num_nodes + 1 entries")
+    if edgeToColumn.numel() < E or edgeToRow.numel() < E:
+        raise RuntimeError("edgeToColumn / edgeToRow are shorter than edgeList")
+    handle = _c._vp()
+    with torch.cuda.device(dev):
+        st = _c.lib.tcgnn_plan_create(nodePointer.data_ptr(), edgeList.data_ptr(), blockPartition.data_ptr(),
+                                      edgeToColumn.data_ptr(), edgeToRow.data_ptr(), N, E, blockPartition.numel(),
+                                      _stream_handle(dev), _c.ctypes.byref(handle))
+    _c.check(st, "tcgnn_plan_create")
+    _plans[key] = (handle, tensors)
+    while len(_plans) > _PLAN_CACHE_SIZE:
+        _, (old, _keep) = _plans.popitem(last=False)
+        torch.cuda.synchronize()  # kernels still reading the evicted plan must finish first
+        _c.lib.tcgnn_plan_destroy(old)
+    return handle
+
+
+def clear_plan_cache():
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    while _plans:
+        _, (old, _keep) = _plans.popitem()
+        _c.lib.tcgnn_plan_destroy(old)
+    _workspaces.clear()
+
+
+def plan_info(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """Not part of the reference API: statistics of the packed tile stream (dict)."""
+    info = _c.PlanInfo()
+    _c.check(_c.lib.tcgnn_plan_get_info(_plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow),
+                                        _c.ctypes.byref(info)), "tcgnn_plan_get_info")
+    return {f: getattr(info, f) for f, _ in info._fields_}
+
+
+def _workspace(plan, D, device):
+    need = _c.lib.tcgnn_workspace_bytes(plan, D)
+    key = (device.index, _stream_handle(device))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    off = (-ws.data_ptr()) % 256
+    return ws.data_ptr() + off, ws.numel() - off
+
+
+# ---------------------------------------------------------------- sparse-graph translation
+
+def _report(tc_blocks):
+    # the reference prints exactly this from C (TCGNN.cpp:225); 1_log2csv.py-style scrapers and the
+    # committed logs (logs/RTX3090_GCN.log:1-2) rely on the two lines
+    sys.stdout.write("TC_Blocks:\t%d\nExp_Edges:\t%d\n" % (tc_blocks, tc_blocks * 8 * 16))
+    sys.stdout.flush()
+
+
+def preprocess(edgeList, nodePointer, num_nodes, blockSize_h, blockSize_w, blockPartition, edgeToColumn, edgeToRow):
+    """Host SGT: fills blockPartition / edgeToColumn / edgeToRow in place (CPU int32 tensors)."""
+    names = ("edgeList", "nodePointer", "blockPartition", "edgeToColumn", "edgeToRow")
+    for t, n in zip((edgeList, nodePointer, blockPartition, edgeToColumn, edgeToRow), names):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s must be a torch.Tensor" % n)
+        if t.is_cuda:
+            raise RuntimeError("%s must be a CPU tensor (use preprocess_gpu for device tensors)" % n)
+        _check_int(t, n)
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % n)
+    num_nodes = int(num_nodes)
+    if nodePointer.numel() < num_nodes + 1:
+        raise RuntimeError("nodePointer holds %d entries, need num_nodes + 1 = %d" % (nodePointer.numel(), num_nodes + 1))
+    E = int(nodePointer[num_nodes])
+    if edgeList.numel() < E or edgeToColumn.numel() < E or edgeToRow.numel() < E:
+        raise RuntimeError("edgeList / edgeToColumn / edgeToRow hold fewer than nodePointer[num_nodes] = %d entries" % E)
+    n = _c._i64(0)
+    st = _c.lib.tcgnn_preprocess(edgeList.data_ptr(), nodePointer.data_ptr(), num_nodes, int(blockSize_h), int(blockSize_w),
+                                 blockPartition.data_ptr(), blockPartition.numel(), edgeToColumn.data_ptr(),
+                                 edgeToRow.data_ptr(), _c.ctypes.byref(n), 0)
+    _c.check(st, "tcgnn_preprocess")
+    _report(n.value)
+
+
+def preprocess_gpu(edgeList, nodePointer, num_nodes, blockSize_h, blockSize_w, blockPartition, edgeToColumn, edgeToRow):
+    """Device SGT: same outputs as preprocess, all tensors on the GPU."""
+    names = ("edgeList", "nodePointer", "blockPartition", "edgeToColumn", "edgeToRow")
+    for t, n in zip((edgeList, nodePointer, blockPartition, edgeToColumn, edgeToRow), names):
+        _check_input(t, n)
+        _check_int(t, n)
+    num_nodes = int(num_nodes)
+    if nodePointer.numel() < num_nodes + 1:
+        raise RuntimeError("nodePointer holds %d entries, need num_nodes + 1 = %d" % (nodePointer.numel(), num_nodes + 1))
+    E = edgeList.numel()
+    if edgeToColumn.numel() < E or edgeToRow.numel() < E:
+        raise RuntimeError("edgeToColumn / edgeToRow are shorter than edgeList")
+    n = _c._i64(0)
+    dev = edgeList.device
+    with torch.cuda.device(dev):
+        st = _c.lib.tcgnn_preprocess_gpu(edgeList.data_ptr(), nodePointer.data_ptr(), num_nodes, E, int(blockSize_h),
+                                         int(blockSize_w), blockPartition.data_ptr(), blockPartition.numel(),
+                                         edgeToColumn.data_ptr(), edgeToRow.data_ptr(), _c.ctypes.byref(n), _stream_handle(dev))
+    _c.check(st, "tcgnn_preprocess_gpu")
+    _report(n.value)
+
+
+# ---------------------------------------------------------------- the hot path
+
+def _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    _check_input(input, "input")
+    _check_input(nodePointer, "nodePointer")
+    _check_input(edgeList, "edgeList")
+    _check_input(blockPartition, "blockPartition")
+    _check_input(edgeToColumn, "edgeToColumn")
+    _check_input(edgeToRow, "edgeToRow")
+    _check_float(input, "input")
+    if input.dim() != 2:
+        raise RuntimeError("input must be [num_nodes, embedding_dim]")
+    N = nodePointer.numel() - 1
+    if input.size(0) != N:
+        raise RuntimeError("input has %d rows but nodePointer describes %d nodes" % (input.size(0), N))
+    if input.device != nodePointer.device:
+        raise RuntimeError("input and nodePointer are on different devices")
+
+
+def forward(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """SpMM  Y = A_bin @ input  (GCN / GIN / SAG aggregation, forward and backward)."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    dev = input.device
+    N, D = input.shape
+    out = torch.empty_like(input)
+    if N == 0 or D == 0:
+        return [out]
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_spmm(plan, input.data_ptr(), out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_spmm")
+    return [out]
+
+
+def forward_AGNN(input, nodePointer, edgeList, edgeAttention, blockPartition, edgeToColumn, edgeToRow):
+    """SpMM with edge values  Y = A_val @ input,  A_val[row(e), col(e)] = edgeAttention[0, e]."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    _check_input(edgeAttention, "edgeAttention")
+    _check_float(edgeAttention, "edgeAttention")
+    dev = input.device
+    N, D = input.shape
+    E = edgeList.numel()
+    # [n_heads, E]; every head's launch in the reference reads row 0 and overwrites the same output
+    # (TCGNN_kernel.cu:253-268, :529), so only row 0 is meaningful
+    if edgeAttention.numel() < E:
+        raise RuntimeError("edgeAttention holds %d values for %d edges" % (edgeAttention.numel(), E))
+    out = torch.empty_like(input)
+    if N == 0 or D == 0:
+        return [out]
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_spmm_val(plan, input.data_ptr(), edgeAttention.data_ptr(), out.data_ptr(), D, ws, ws_bytes,
+                                   _stream_handle(dev))
+    _c.check(st, "tcgnn_spmm_val")
+    return [out]
+
+
+def forward_ef(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """SDDMM  ef[e] = <input[row(e)], input[col(e)]>  for every CSR edge, fp32 [E]."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    dev = input.device
+    N, D = input.shape
+    E = edgeList.numel()
+    out = torch.empty(E, dtype=torch.float32, device=dev)
+    if E == 0:
+        return [out]
+    if D == 0:
+        return [out.zero_()]
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_sddmm(plan, input.data_ptr(), out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_sddmm")
+    return [out]
+
+
+backward = forward        # TCGNN.cpp:270
+backward_ef = forward_ef  # TCGNN.cpp:271

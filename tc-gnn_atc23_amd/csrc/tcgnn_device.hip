@@ -1,0 +1,723 @@
+// tcgnn_device.hip - gfx950 (MI355X / CDNA4) kernels and C-ABI launchers of libtcgnn_hip.so.
+//
+// What replaces what (reference paths relative to /root/reference):
+//   pack_kernel        legacy metadata -> packed tile stream.  The reference has no such step: its
+//                      kernels rebuild every 16x8 tile by rescanning ALL edges of the window once
+//                      per tile (TCGNN_kernel.cu:400-408, :656-663).  Packing once per graph
+//                      removes that O(tiles x edges) work from every call.
+//   absmax / convert   fp32 X -> fp16 staging copy, scaled by a per-call power of two so the
+//                      10-bit-mantissa rounding equals the reference's TF32 rounding
+//                      (wmma::__float_to_tf32, TCGNN_kernel.cu:438-444) without fp16's range limit.
+//   spmm_kernel        TCGNN_kernel.cu:336-454 (binary A) and :459-578 (edge-valued A).
+//   sddmm_kernel       TCGNN_kernel.cu:584-727.
+//   *_csr_kernel       slow-but-correct HIP paths for CSRs whose rows are not strictly increasing
+//                      (the packed edge-offset table assumes canonical rows).
+//
+// Data flow of one SpMM workgroup (one 16-row window, 1 or 4 wavefronts):
+//   each wavefront walks its share of the window's 16x32 tiles; per tile it
+//     (1) reads 32 source-row ids and a 16x32 adjacency bitmask (coalesced, 192 B),
+//     (2) gathers the 32 fp16 feature rows straight into LDS with per-lane-addressed
+//         global_load_lds_dwordx4 (no VGPR round trip, no ds_write), in an XOR-swizzled image,
+//     (3) synthesises the MFMA A fragment from the bitmask in registers,
+//     (4) reads B fragments with ds_read_b64_tr_b16 (hardware transpose: K runs over gathered
+//         rows, which are the LDS rows) and issues one v_mfma_f32_16x16x32_f16 per 16 columns;
+//   partial accumulators of the wavefronts are summed through LDS in a fixed order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "tcgnn.h"
+#include "tcgnn_internal.h"
+
+using namespace tcgnn;
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_raw;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(TCGNN_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct tcgnn_plan {
+    int32_t N = 0, nw = 0, nw_eff = 0;
+    int64_t E = 0, tc_blocks = 0, total_wb = 0;
+    int canonical = 0, waves = 1;
+    const int32_t *rowptr = nullptr, *col = nullptr, *bp = nullptr, *e2c = nullptr, *e2r = nullptr; // borrowed
+    int64_t* d_wb_ptr = nullptr;  // [nw_eff + 1] first wide block of each window
+    int32_t* d_order = nullptr;   // [nw_eff] window ids, heaviest first
+    int32_t* d_cols = nullptr;    // [total_wb][32] source row of each condensed column (N = none)
+    uint32_t* d_mask = nullptr;   // [total_wb][16] bit c of word r: A[r][c] != 0
+    int32_t* d_ebase = nullptr;   // [total_wb][16] CSR position of the first edge of row r in the tile
+    size_t bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+// Power-of-two exponent k such that absmax * 2^k lies in [2^14, 2^15): fp16-safe (max 65504) with
+// 29 binades of normal range below the largest element.  0 for all-zero / non-finite data.
+__device__ __forceinline__ int scale_exp_from_bits(uint32_t b) {
+    if (b == 0u || b >= 0x7f800000u) return 0;
+    int e = (int)(b >> 23) - 127;
+    int k = 14 - e;
+    return k > 126 ? 126 : (k < -126 ? -126 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
+// wmma::__float_to_tf32 (cvt.rna.tf32.f32, TCGNN_kernel.cu:441-444) does.  The result has at most
+// 11 significant bits, so the following fp32 -> fp16 conversion is exact for every element within
+// 2^-28 of the (scaled) maximum; fp16's default nearest-EVEN would differ on ties (about one
+// element in 2^13), which shows up as 2^-10-sized output differences.
+__device__ __forceinline__ _Float16 to_half_rna(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7f800000u) != 0x7f800000u) u = (u + 0x1000u) & 0xffffe000u;
+    return (_Float16)__uint_as_float(u);
+}
+
+// LDS image of one tile: 32 gathered rows x (NT*16) halves, addressed in 16-byte slots.
+// global_load_lds lands lane l of an instruction at slot (instr*64 + l), so the image is any
+// bijection (row, slot-in-row) <-> slot we like, applied on the SOURCE address.  The bijection is
+// chosen so that every 32-lane pass of ds_read_b64_tr_b16 (8 rows x 32 B) touches all 64 banks once.
+template <int NT>
+struct TileImage {
+    static constexpr int C = 2 * NT; // 16-byte slots per row
+    __device__ static __forceinline__ int slot(int row, int c) {
+        if constexpr (NT == 1) {
+            int rp = (row & ~0xC) | ((row & 4) << 1) | ((row & 8) >> 1); // swap row bits 2 and 3
+            return rp * 2 + c;
+        } else if constexpr (NT == 2) {
+            return row * 4 + (c ^ (((row >> 3) & 1) << 1));
+        } else if constexpr (NT == 4) {
+            return row * 8 + (c ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
+        } else if constexpr (NT == 8) {
+            return row * 16 + (c ^ (((row & 3) | (((row >> 3) & 1) << 2)) << 1));
+        } else {
+            return row * C + c;
+        }
+    }
+    __device__ static __forceinline__ void unslot(int q, int& row, int& c) {
+        if constexpr (NT == 1) {
+            int rp = q >> 1;
+            row = (rp & ~0xC) | ((rp & 4) << 1) | ((rp & 8) >> 1);
+            c = q & 1;
+        } else if constexpr (NT == 2) {
+            row = q >> 2;
+            c = (q & 3) ^ (((row >> 3) & 1) << 1);
+        } else if constexpr (NT == 4) {
+            row = q >> 3;
+            c = (q & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
+        } else if constexpr (NT == 8) {
+            row = q >> 4;
+            c = (q & 15) ^ (((row & 3) | (((row >> 3) & 1) << 2)) << 1);
+        } else {
+            row = q / C;
+            c = q - row * C;
+        }
+    }
+};
+
+__device__ __forceinline__ half4 lds_read_tr16(const char* p) {
+    fp16x4_raw v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4_raw*)(p));
+    return __builtin_bit_cast(half4, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// pack: legacy (nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow) -> tile stream
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ col,
+                                                   const int32_t* __restrict__ e2c,
+                                                   const int32_t* __restrict__ e2r,
+                                                   const int64_t* __restrict__ wb_ptr, int32_t N,
+                                                   int32_t* cols, uint32_t* mask, int32_t* ebase,
+                                                   int32_t* flags) {
+    const int w = blockIdx.x;
+    const int64_t n0 = (int64_t)w * kWinRows;
+    const int64_t n1 = n0 + kWinRows < N ? n0 + kWinRows : N;
+    const int64_t base = wb_ptr[w];
+    const int64_t nwb = wb_ptr[w + 1] - base;
+    for (int64_t k = threadIdx.x; k < nwb * kWbCols; k += blockDim.x) cols[base * kWbCols + k] = N;
+    for (int64_t k = threadIdx.x; k < nwb * kWinRows; k += blockDim.x) {
+        mask[base * kWinRows + k] = 0u;
+        ebase[base * kWinRows + k] = 0;
+    }
+    __syncthreads();
+    if (n0 >= N) return;
+    const int64_t e0 = rowptr[n0], e1 = rowptr[n1];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const int c = e2c[e];
+        const int r = e2r[e] - (int)n0;
+        const int v = col[e];
+        if (c < 0 || (int64_t)c >= nwb * kWbCols || r < 0 || r >= kWinRows || v < 0 || v >= N) {
+            flags[0] = 1;
+            continue;
+        }
+        const int64_t tile = base + (c >> 5);
+        cols[tile * kWbCols + (c & 31)] = v; // duplicates of a column write the same id
+        atomicOr(&mask[tile * kWinRows + r], 1u << (c & 31));
+        bool first_in_tile_row = true;
+        if (e > e0 && e2r[e - 1] - (int)n0 == r) {
+            const int cp = e2c[e - 1];
+            if (cp >= c) flags[1] = 1; // row not strictly increasing: edge-offset table unusable
+            first_in_tile_row = (cp >> 5) != (c >> 5);
+        }
+        if (first_in_tile_row) ebase[tile * kWinRows + r] = (int32_t)e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// staging: absmax + fp32 -> scaled fp16 copy with a zero sentinel row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, int64_t n,
+                                                     uint32_t* out) {
+    uint32_t m = 0;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t k = gid; k < n4; k += gsz) {
+            const float4 v = p4[k];
+            m = max(m, __float_as_uint(v.x) & 0x7fffffffu);
+            m = max(m, __float_as_uint(v.y) & 0x7fffffffu);
+            m = max(m, __float_as_uint(v.z) & 0x7fffffffu);
+            m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+        }
+        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+    } else {
+        for (int64_t k = gid; k < n; k += gsz) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// One thread per 16-byte output chunk (8 halves).  Rows: N real + 1 all-zero sentinel row that
+// padding columns of the tile stream point at (the reference zero-fills those, :423-424).
+template <bool VEC>
+__global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
+                                                      int32_t D, int32_t Dpad,
+                                                      _Float16* __restrict__ X16,
+                                                      const uint32_t* __restrict__ hdr) {
+    const int cpr = Dpad >> 3;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = ((int64_t)N + 1) * cpr;
+    if (q >= total) return;
+    const int64_t row = q / cpr;
+    const int d0 = (int)(q - row * cpr) * 8;
+    const float s = pow2f(scale_exp_from_bits(hdr[0]));
+    half8 o;
+    if (row < N && VEC && d0 + 8 <= D) {
+        const float4* src = reinterpret_cast<const float4*>(X + row * D + d0);
+        const float4 a = src[0], b = src[1];
+        o[0] = to_half_rna(a.x * s); o[1] = to_half_rna(a.y * s); o[2] = to_half_rna(a.z * s); o[3] = to_half_rna(a.w * s);
+        o[4] = to_half_rna(b.x * s); o[5] = to_half_rna(b.y * s); o[6] = to_half_rna(b.z * s); o[7] = to_half_rna(b.w * s);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = d0 + j;
+            o[j] = (row < N && d < D) ? to_half_rna(X[row * D + d] * s) : (_Float16)0.0f;
+        }
+    }
+    *reinterpret_cast<half8*>(X16 + row * Dpad + d0) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// SpMM:  Y[window] = A_tile-stream * X16
+// ------------------------------------------------------------------------------------------
+struct SpmmArgs {
+    const int64_t* wb_ptr;
+    const int32_t* order;
+    const int32_t* cols;
+    const uint32_t* mask;
+    const int32_t* ebase;
+    const _Float16* x16;
+    const float* edge_val;
+    const uint32_t* hdr;
+    float* y;
+    int32_t N, D, stride, chunk0;
+};
+
+template <int NT, int WAVES, bool VAL>
+__global__ __launch_bounds__(WAVES * 64) void spmm_kernel(const SpmmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_BYTES = NT * 1024;
+    constexpr int NBUF = 2;
+    using Img = TileImage<NT>;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int w = a.order[blockIdx.x];
+    const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims; // first feature column of this pass
+    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+    const int64_t stride = a.stride;
+    char* ring = smem + wave * (NBUF * TILE_BYTES);
+
+    const int kx = scale_exp_from_bits(a.hdr[0]);
+    const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
+    const float sa = pow2f(ka);
+
+    // which (gathered row, 16-byte piece) this lane fetches in each of the NT DMA instructions
+    int drow[NT], dbyte[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        int c;
+        Img::unslot(k * 64 + lane, drow[k], c);
+        dbyte[k] = c * 16;
+    }
+    // where this lane points ds_read_b64_tr_b16 for slice s, row half h: row 8g+4h+(i>>2),
+    // halves 16s+4(i&3)..+3  -> slot 2s+((i>>1)&1), byte (i&1)*8
+    const int rrow = 8 * g + (i >> 2);
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const char* xbase = reinterpret_cast<const char*>(a.x16 + coloff);
+    auto issue = [&](int64_t t, char* dst) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int cid = a.cols[t * kWbCols + drow[k]];
+            const char* src = xbase + ((int64_t)cid * stride) * 2 + dbyte[k];
+            __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(dst + k * 1024), 16, 0, 0);
+        }
+    };
+
+    int64_t t = tb + wave;
+    int buf = 0;
+    if (t < te) issue(t, ring);
+    while (t < te) {
+        const int64_t tn = t + WAVES;
+        // ---- A fragment of tile t: lane (g, r=i) holds A[r][8g .. 8g+7]
+        const uint32_t m = a.mask[t * kWinRows + i];
+        const uint32_t mb = (m >> (8 * g)) & 0xffu;
+        half8 af;
+        if constexpr (VAL) {
+            const int eb = a.ebase[t * kWinRows + i] + __popc(m & ((1u << (8 * g)) - 1u));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool on = (mb >> j) & 1u;
+                const int e = eb + __popc(mb & ((1u << j) - 1u));
+                const float v = on ? a.edge_val[e] * sa : 0.0f;
+                af[j] = to_half_rna(v);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+        if (tn < te) issue(tn, ring + (buf ^ 1) * TILE_BYTES);
+        // ---- B fragments: rows of the LDS image are K; the transpose read hands lane (g,i)
+        //      K = 8g+4h+{0..3} of column 16s+i.  (compiler inserts the vmcnt wait for the DMA)
+        const char* tile = ring + buf * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int c = 2 * s + ((i >> 1) & 1);
+            const half4 lo = lds_read_tr16(tile + Img::slot(rrow, c) * 16 + (i & 1) * 8);
+            const half4 hi = lds_read_tr16(tile + Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
+            const half8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
+        }
+        t = tn;
+        buf ^= 1;
+    }
+
+    // ---- combine the wavefronts' partial sums in a fixed order and store
+    const float inv = pow2f(-kx) * (VAL ? pow2f(-ka) : 1.0f); // |kx+ka| may exceed 126: two factors
+    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f;
+    (void)inv;
+    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
+    if constexpr (WAVES > 1) {
+        __syncthreads(); // every wave is done with its ring
+        floatx4* red = reinterpret_cast<floatx4*>(smem);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
+        __syncthreads();
+        for (int s = wave; s < NT; s += WAVES) {
+            floatx4 v = red[s * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) {
+                const floatx4 o = red[(ww * NT + s) * 64 + lane];
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            const int colg = coloff + 16 * s + i;
+            if (colg < a.D) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int colg = coloff + 16 * s + i;
+            if (colg < a.D) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii] * inv1 * inv2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SDDMM:  ef[e] = <X16[row e], X16[col e]>
+// ------------------------------------------------------------------------------------------
+struct SddmmArgs {
+    const int64_t* wb_ptr;
+    const int32_t* order;
+    const int32_t* cols;
+    const uint32_t* mask;
+    const int32_t* ebase;
+    const _Float16* x16;
+    const uint32_t* hdr;
+    float* ef;
+    int32_t N, Dpad, stride;
+};
+
+// KS = number of 32-wide k steps held in registers for the window rows (0: loop at run time and
+// re-read them per tile; used for D > 128).
+template <int KS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int w = a.order[blockIdx.x];
+    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+    const int64_t stride = a.stride;
+    const int kx = scale_exp_from_bits(a.hdr[0]);
+    const float inv = pow2f(-kx);
+    const int ksteps = (a.Dpad + 31) >> 5;
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
+    int64_t arow = (int64_t)w * kWinRows + i;
+    if (arow > a.N) arow = a.N;
+    const _Float16* ap = a.x16 + arow * stride + 8 * g;
+    half8 af[KS > 0 ? KS : 1];
+    if constexpr (KS > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
+    }
+
+    for (int64_t t = tb + wave; t < te; t += WAVES) {
+        const uint4 m4 = *reinterpret_cast<const uint4*>(a.mask + t * kWinRows + 4 * g);
+        const int4 eb4 = *reinterpret_cast<const int4*>(a.ebase + t * kWinRows + 4 * g);
+        const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const int ee[4] = {eb4.x, eb4.y, eb4.z, eb4.w};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const uint32_t anyrow = ((m4.x | m4.y | m4.z | m4.w) >> (16 * sub)) & 0xffffu;
+            if (!__any(anyrow != 0u)) continue; // no edge lands in this 16-column half
+            const int cid = a.cols[t * kWbCols + 16 * sub + i];
+            const _Float16* bp = a.x16 + (int64_t)cid * stride + 8 * g;
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KS > 0) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const half8 bf = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf, acc, 0, 0, 0);
+                }
+            } else {
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const bool ok = ks * 32 + 8 * g < a.Dpad;
+                    const half8 av = ok ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
+                    const half8 bf = ok ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
+                }
+            }
+            // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
+            const int bit = 16 * sub + i;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                if ((mm[ii] >> bit) & 1u) {
+                    const int e = ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
+                    a.ef[e] = acc[ii] * inv * inv;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fallbacks for non-canonical CSR rows (unsorted or duplicated column ids)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ X, float* Y,
+                                                           int32_t N, int32_t D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+        for (int64_t e = e0; e < e1; ++e) s += val[e] * X[(int64_t)col[e] * D + d];
+        Y[row * D + d] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col,
+                                                        const float* __restrict__ X, float* ef,
+                                                        int32_t N, int32_t D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = X + row * D;
+    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+        const float* xc = X + (int64_t)col[e] * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += xr[d] * xc[d];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) ef[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch tables
+// ------------------------------------------------------------------------------------------
+template <int NT, int WAVES, bool VAL>
+static hipError_t launch_spmm_one(const SpmmArgs& args, int nwin, int nchunks, hipStream_t stream) {
+    const size_t lds = (size_t)WAVES * 2 * NT * 1024;
+    hipLaunchKernelGGL((spmm_kernel<NT, WAVES, VAL>), dim3((unsigned)nwin, (unsigned)nchunks), dim3(WAVES * 64), lds, stream, args);
+    return hipGetLastError();
+}
+
+template <int WAVES, bool VAL>
+static hipError_t launch_spmm_nt(int nt, const SpmmArgs& args, int nwin, int nchunks, hipStream_t stream) {
+    switch (nt) {
+        case 1: return launch_spmm_one<1, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 2: return launch_spmm_one<2, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 3: return launch_spmm_one<3, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 4: return launch_spmm_one<4, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 5: return launch_spmm_one<5, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 6: return launch_spmm_one<6, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 7: return launch_spmm_one<7, WAVES, VAL>(args, nwin, nchunks, stream);
+        case 8: return launch_spmm_one<8, WAVES, VAL>(args, nwin, nchunks, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static hipError_t launch_spmm_any(bool val, int waves, int nt, const SpmmArgs& args, int nwin, int nchunks, hipStream_t stream) {
+    if (waves == 4) return val ? launch_spmm_nt<4, true>(nt, args, nwin, nchunks, stream) : launch_spmm_nt<4, false>(nt, args, nwin, nchunks, stream);
+    return val ? launch_spmm_nt<1, true>(nt, args, nwin, nchunks, stream) : launch_spmm_nt<1, false>(nt, args, nwin, nchunks, stream);
+}
+
+template <int WAVES>
+static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipStream_t stream) {
+    const dim3 grid((unsigned)nwin), block(WAVES * 64);
+    switch (ks) {
+        case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES>), grid, block, 0, stream, args); break;
+        case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES>), grid, block, 0, stream, args); break;
+        case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES>), grid, block, 0, stream, args); break;
+        case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES>), grid, block, 0, stream, args); break;
+        default: hipLaunchKernelGGL((sddmm_kernel<0, WAVES>), grid, block, 0, stream, args); break;
+    }
+    return hipGetLastError();
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static constexpr size_t kHdrBytes = 256;
+
+static size_t workspace_bytes_for(int32_t N, int32_t D) {
+    const size_t dpad = (size_t)round_up(D, 16);
+    const size_t body = ((size_t)N + 1) * dpad * sizeof(_Float16);
+    return kHdrBytes + ((body + 255) / 256) * 256;
+}
+
+// enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
+static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
+                          void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
+                          const _Float16** x16_out, int* dpad_out) {
+    const size_t need = workspace_bytes_for(plan->N, D);
+    if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
+        return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
+    uint32_t* hdr = static_cast<uint32_t*>(ws);
+    _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
+    const int dpad = round_up(D, 16);
+    HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
+    const int64_t nx = (int64_t)plan->N * D;
+    if (nx > 0) {
+        const int grid = (int)std::min<int64_t>(2048, (nx / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
+    }
+    if (d_val && plan->E > 0) {
+        const int grid = (int)std::min<int64_t>(2048, (plan->E / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1);
+    }
+    const int64_t chunks = ((int64_t)plan->N + 1) * (dpad / 8);
+    const unsigned cgrid = (unsigned)((chunks + 255) / 256);
+    const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
+    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->N, D, dpad, x16, hdr);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->N, D, dpad, x16, hdr);
+    HIP_TRY(hipGetLastError());
+    *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad;
+    return TCGNN_OK;
+}
+
+static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
+                    void* ws, size_t ws_bytes, void* stream_v) {
+    if (!plan || D < 1 || (plan->N > 0 && (!d_X || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (plan->N == 0) return TCGNN_OK;
+    if ((int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
+        HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
+    if (d_val && !plan->canonical) {
+        hipLaunchKernelGGL(spmm_val_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream,
+                           plan->rowptr, plan->col, d_val, d_X, d_Y, plan->N, D);
+        HIP_TRY(hipGetLastError());
+        return TCGNN_OK;
+    }
+    const uint32_t* hdr; const _Float16* x16; int dpad;
+    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad);
+    if (rc) return rc;
+    if (plan->nw_eff == 0) return TCGNN_OK;
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, dpad, 0};
+    const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
+    if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, 8, a, plan->nw_eff, nfull, stream)); }
+    if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, rem, a, plan->nw_eff, 1, stream)); }
+    return TCGNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int tcgnn_plan_destroy(tcgnn_plan* plan) {
+    if (!plan) return TCGNN_OK;
+    (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
+    (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase);
+    delete plan;
+    return TCGNN_OK;
+}
+
+int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
+                      const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
+                      const int32_t* d_edgeToRow, int32_t num_nodes, int64_t num_edges,
+                      int32_t num_windows, void* stream_v, tcgnn_plan** plan_out) {
+    if (!plan_out) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_create: plan_out is null");
+    *plan_out = nullptr;
+    if (num_nodes < 0 || num_edges < 0 || num_windows < 0 || !d_nodePointer ||
+        (num_windows > 0 && !d_blockPartition) || (num_edges > 0 && (!d_edgeList || !d_edgeToColumn || !d_edgeToRow)))
+        return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_create: null array or negative size");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    tcgnn_plan* p = new (std::nothrow) tcgnn_plan();
+    if (!p) return fail(TCGNN_ERR_OOM, "tcgnn_plan_create: host allocation failed");
+    p->N = num_nodes; p->E = num_edges; p->nw = num_windows;
+    p->nw_eff = (int32_t)std::min<int64_t>(num_windows, ((int64_t)num_nodes + kWinRows - 1) / kWinRows);
+    p->rowptr = d_nodePointer; p->col = d_edgeList; p->bp = d_blockPartition; p->e2c = d_edgeToColumn; p->e2r = d_edgeToRow;
+    const int nw = p->nw_eff;
+    std::vector<int32_t> bp((size_t)std::max(nw, 1));
+    auto bail = [&](int rc) { tcgnn_plan_destroy(p); return rc; };
+    if (nw > 0) {
+        hipError_t e = hipMemcpyAsync(bp.data(), d_blockPartition, (size_t)nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "read blockPartition: %s", hipGetErrorString(e)));
+    }
+    std::vector<int64_t> wb_ptr((size_t)nw + 1, 0);
+    for (int w = 0; w < nw; ++w) {
+        if (bp[(size_t)w] < 0) return bail(fail(TCGNN_ERR_BAD_GRAPH, "blockPartition[%d] = %d is negative", w, bp[(size_t)w]));
+        p->tc_blocks += bp[(size_t)w];
+        wb_ptr[(size_t)w + 1] = wb_ptr[(size_t)w] + (bp[(size_t)w] + 3) / 4;
+    }
+    p->total_wb = wb_ptr[(size_t)nw];
+    std::vector<int32_t> order((size_t)std::max(nw, 1));
+    std::iota(order.begin(), order.begin() + nw, 0);
+    std::stable_sort(order.begin(), order.begin() + nw, [&](int32_t x, int32_t y) { return bp[(size_t)x] > bp[(size_t)y]; });
+    p->waves = (nw > 0 && p->total_wb >= (int64_t)6 * nw) ? 4 : 1;
+
+    const size_t n_wb = (size_t)std::max<int64_t>(p->total_wb, 1);
+    const size_t b_ptr = ((size_t)nw + 1) * sizeof(int64_t), b_ord = (size_t)std::max(nw, 1) * sizeof(int32_t);
+    const size_t b_cols = n_wb * kWbCols * sizeof(int32_t), b_mask = n_wb * kWinRows * sizeof(uint32_t), b_eb = n_wb * kWinRows * sizeof(int32_t);
+    int32_t* d_flags = nullptr;
+    hipError_t e = hipMalloc(&p->d_wb_ptr, b_ptr);
+    if (e == hipSuccess) e = hipMalloc(&p->d_order, b_ord);
+    if (e == hipSuccess) e = hipMalloc(&p->d_cols, b_cols);
+    if (e == hipSuccess) e = hipMalloc(&p->d_mask, b_mask);
+    if (e == hipSuccess) e = hipMalloc(&p->d_ebase, b_eb);
+    if (e == hipSuccess) e = hipMalloc(&d_flags, 2 * sizeof(int32_t));
+    if (e != hipSuccess) { (void)hipFree(d_flags); return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "plan allocation (%zu bytes): %s", b_ptr + b_ord + b_cols + b_mask + b_eb, hipGetErrorString(e))); }
+    p->bytes = b_ptr + b_ord + b_cols + b_mask + b_eb;
+    int32_t flags[2] = {0, 0};
+    e = hipMemcpyAsync(p->d_wb_ptr, wb_ptr.data(), b_ptr, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && nw > 0) e = hipMemcpyAsync(p->d_order, order.data(), (size_t)nw * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), stream);
+    if (e == hipSuccess && nw > 0) {
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)nw), dim3(256), 0, stream, d_nodePointer, d_edgeList, d_edgeToColumn,
+                           d_edgeToRow, p->d_wb_ptr, num_nodes, p->d_cols, p->d_mask, p->d_ebase, d_flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); // host vectors above must outlive the copies
+    (void)hipFree(d_flags);
+    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build: %s", hipGetErrorString(e)));
+    if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
+    p->canonical = flags[1] ? 0 : 1;
+    *plan_out = p;
+    return TCGNN_OK;
+}
+
+int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
+    if (!plan || !info) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_get_info: null argument");
+    info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
+    info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
+    info->canonical = plan->canonical; info->waves_per_window = plan->waves;
+    return TCGNN_OK;
+}
+
+size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
+    if (!plan || D < 1) return 0;
+    return workspace_bytes_for(plan->N, D);
+}
+
+int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
+    return run_spmm(plan, d_X, nullptr, d_Y, D, ws, ws_bytes, stream);
+}
+
+int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y, int32_t D,
+                   void* ws, size_t ws_bytes, void* stream) {
+    if (plan && plan->E > 0 && !d_edge_val) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_val: edge values are null");
+    return run_spmm(plan, d_X, plan && plan->E > 0 ? d_edge_val : nullptr, d_Y, D, ws, ws_bytes, stream);
+}
+
+int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D, void* ws, size_t ws_bytes, void* stream_v) {
+    if (!plan || D < 1 || (plan->N > 0 && !d_X) || (plan->E > 0 && !d_ef)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_sddmm: null argument or D < 1");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (plan->E == 0 || plan->N == 0) return TCGNN_OK;
+    if (!plan->canonical) {
+        hipLaunchKernelGGL(sddmm_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream, plan->rowptr, plan->col, d_X, d_ef, plan->N, D);
+        HIP_TRY(hipGetLastError());
+        return TCGNN_OK;
+    }
+    if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
+    const uint32_t* hdr; const _Float16* x16; int dpad;
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad);
+    if (rc) return rc;
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, dpad, dpad};
+    const int ks = (dpad + 31) / 32;
+    hipError_t e = plan->waves == 4 ? launch_sddmm_ks<4>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1>(ks, a, plan->nw_eff, stream);
+    HIP_TRY(e);
+    return TCGNN_OK;
+}
+
+
+} // extern "C"

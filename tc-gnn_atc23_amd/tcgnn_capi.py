@@ -1,0 +1,55 @@
+"""ctypes binding of libtcgnn_hip.so (the C ABI declared in include/tcgnn.h).
+
+There is no CPU fallback: if the shared library has not been built the import fails loudly, and a
+non-zero status from any entry point raises RuntimeError carrying tcgnn_last_error().
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtcgnn_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libtcgnn_hip.so is not built (%s). Build it with `make -C %s` or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`; there is no fallback path."
+        % (LIB_PATH, os.path.join(_HERE, "csrc")))
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_i32p = ctypes.c_void_p  # raw addresses (host or device) travel as integers
+_vp = ctypes.c_void_p
+_i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("num_nodes", _i32), ("num_windows", _i32), ("num_edges", _i64), ("tc_blocks", _i64),
+                ("wide_blocks", _i64), ("plan_bytes", _i64), ("canonical", _i32), ("waves_per_window", _i32)]
+
+
+# every symbol include/tcgnn.h declares, with its signature
+SIGNATURES = {
+    "tcgnn_abi_version": (ctypes.c_int, []),
+    "tcgnn_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "tcgnn_last_error": (ctypes.c_char_p, []),
+    "tcgnn_preprocess": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _i32]),
+    "tcgnn_preprocess_gpu": (ctypes.c_int, [_i32p, _i32p, _i32, _i64, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _vp]),
+    "tcgnn_plan_create": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
+    "tcgnn_plan_destroy": (ctypes.c_int, [_vp]),
+    "tcgnn_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfo)]),
+    "tcgnn_workspace_bytes": (_sz, [_vp, _i32]),
+    "tcgnn_spmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "tcgnn_spmm_val": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "tcgnn_sddmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib.tcgnn_last_error().decode("utf-8", "replace")
+        kind = lib.tcgnn_status_string(status).decode()
+        raise RuntimeError("%s failed: %s (%s)" % (what, kind, msg))
