@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""bench.py - the headline measurement of BASELINE.json:
+    "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X".
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1: plain python; N > 1: torchrun)
+
+One STEP = one pass of the hot path over one batch of synthetic input = one `TCGNN.forward` call
+(fp16 staging pass + the SpMM kernel) on the Reddit-shaped graph at D = 64, inputs resident in HBM.
+`value` = traversed edges per second of the whole job in GTEPS (E * K * N / t).  The other
+quantities the metric names are measured in the same run and reported under `extra`
+(SDDMM and SpMM-AGNN GTEPS, GCN / AGNN ms per epoch, host and device SGT times).
+
+workload (config.workload): BASELINE.json configs[2] "Reddit GCN 2-layer hidden=64" -
+N = 232 965 nodes, nnz = 114 615 892, seeded synthetic symmetric graph (no dataset
+or network on the box), features randn, labels ones (dataset.py:115,122).
+
+N > 1 (weak scaling): the papers100M pattern of configs[4] in miniature - the graph has N x 232 965
+nodes, rank p owns the rows of its 232 965 nodes (114.6 M nnz with columns over ALL N x 232 965
+nodes), a step = all-gather of the X row blocks over RCCL + the local SpMM.  Per-GPU work is fixed.
+
+roofline: the SpMM kernel is HBM-bound by its algorithmic bytes B = 4(N+1) + 4E + 8ND
+(SURVEY.md 8d); `achieved` = B / (mean kernel time from HIP events on the launch stream, recorded
+inside the timed steps), `peak` = 8 TB/s (MI355X_MICROARCH.md).  `traffic` is the PMC-measured
+HBM bytes per launch when profiles/ holds a measurement for this workload, else null.
+
+cpu_baseline: the oracle's row-parallel CSR gather-add (the DGL-CPU-style aggregation,
+oracle/tcgnn_oracle.c: oracle_csr_spmm) on the host cores, same graph and D, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--dim", type=int, default=64, help="hidden width D of the timed SpMM")
+    p.add_argument("--shape", type=str, default="reddit")
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; the reported config is scale 1)")
+    p.add_argument("--epochs", type=int, default=10, help="timed epochs of the GCN / AGNN legs")
+    p.add_argument("--no-extra", action="store_true", help="skip SDDMM / epoch / CPU legs (profiling runs)")
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--seed", type=int, default=0)
+    return p.parse_args()
+
+
+def sync_time(fn, steps, warmup, barrier):
+    for _ in range(warmup):
+        fn()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(); barrier()
+    return time.perf_counter() - t0
+
+
+def spmm_bytes(n, e, d):
+    return 4 * (n + 1) + 4 * e + 8 * n * d
+
+
+def sddmm_bytes(n, e, d):
+    return 4 * (n + 1) + 8 * e + 4 * n * d
+
+
+def load_traffic(kernel, workload):
+    """PMC-measured HBM bytes per launch, if a profile for this workload has been committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            for row in json.load(f):
+                if row.get("kernel") == kernel and row.get("workload") == workload:
+                    return row.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def single_gpu(args):
+    import TCGNN
+    import tcgnn_graph as G
+    import tcgnn_harness as H
+    dev = torch.device("cuda:0")
+    n, nnz_target, in_dim, classes = G.SHAPES[args.shape]
+    if args.scale != 1.0:
+        n, nnz_target = int(n * args.scale), int(nnz_target * args.scale * args.scale)
+    D = args.dim
+    t0 = time.perf_counter()
+    rp_d, col_d = G.synthetic_csr(n, nnz_target, seed=args.seed, device=dev)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    E = col_d.numel()
+    nw = (n + 15) // 16
+
+    # ---- sparse-graph translation: host (as main_tcgnn.py:51 does) and device, timed once each
+    rp_h, col_h = rp_d.cpu(), col_d.cpu()
+    bp_h = torch.zeros(nw, dtype=torch.int32); e2c_h = torch.zeros(E, dtype=torch.int32); e2r_h = torch.zeros(E, dtype=torch.int32)
+    e2c_h.fill_(1); e2r_h.fill_(1)  # touch the pages before timing
+    devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); sys.stdout.flush(); os.dup2(devnull, 1)
+    try:
+        t0 = time.perf_counter()
+        TCGNN.preprocess(col_h, rp_h, n, 16, 8, bp_h, e2c_h, e2r_h)
+        host_sgt_ms = (time.perf_counter() - t0) * 1e3
+        bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+        TCGNN.preprocess_gpu(col_d, rp_d, n, 16, 8, bp, e2c, e2r)  # warm (rocPRIM temp allocation)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        TCGNN.preprocess_gpu(col_d, rp_d, n, 16, 8, bp, e2c, e2r)
+        torch.cuda.synchronize(); dev_sgt_ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        sys.stdout.flush(); os.dup2(saved, 1); os.close(saved); os.close(devnull)
+    sgt_equal = bool(torch.equal(bp.cpu(), bp_h) and torch.equal(e2c.cpu(), e2c_h) and torch.equal(e2r.cpu(), e2r_h))
+    meta = (rp_d, col_d, bp, e2c, e2r)
+    info = TCGNN.plan_info(*meta)
+
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    X = torch.randn(n, D, device=dev, generator=g)
+    step = lambda: TCGNN.forward(X, *meta)
+    noop = lambda: None
+
+    # ---- the timed K steps, kernel events recorded inside them
+    for _ in range(args.warmup):
+        step()
+    TCGNN.kernel_timing(*meta, max_calls=args.steps)
+    elapsed = sync_time(step, args.steps, 0, noop)
+    kernel_ms = TCGNN.kernel_timing(*meta)
+    TCGNN.kernel_timing(*meta, max_calls=0)
+    k_mean = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    ms_per_step = elapsed * 1e3 / args.steps
+    gteps = E / (elapsed / args.steps) / 1e9
+    workload = "%s-shape synthetic graph N=%d nnz=%d, SpMM D=%d (GCN aggregation, fwd = bwd)" % (args.shape, n, E, D)
+    roof_b = spmm_bytes(n, E, D)
+    out = {
+        "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
+        "value": round(gteps, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 operands (TF32-equivalent rounding), f32 accumulate, f32 I/O", "data": "synthetic",
+        "config": {"workload": workload, "graph": "seeded uniform symmetric, canonical CSR", "tc_blocks_16x8": info["tc_blocks"],
+                   "reddit_real_tc_blocks_16x8": 13566510, "wide_blocks_16x32": info["wide_blocks"],
+                   "waves_per_window": info["waves_per_window"], "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "kernel": "spmm_kernel<NT=%d,WAVES=%d>" % ((D + 15) // 16 if D <= 128 else 8, info["waves_per_window"]),
+                     "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": load_traffic("spmm_kernel", "%s_d%d" % (args.shape, D)),
+                     "algorithmic_bytes": roof_b, "kernel_ms_mean": round(k_mean, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if kernel_ms else None,
+                     "kernel_launches_timed": len(kernel_ms)},
+    }
+    extra = {"graph_gen_s": round(gen_s, 2), "host_sgt_ms": round(host_sgt_ms, 1), "host_sgt_ns_per_edge": round(host_sgt_ms * 1e6 / E, 2),
+             "device_sgt_ms": round(dev_sgt_ms, 1), "device_sgt_equals_host_sgt": sgt_equal, "plan_bytes": info["plan_bytes"],
+             "staging_plus_launch_ms_per_step": round(ms_per_step - k_mean, 4)}
+
+    if not args.no_extra:
+        def kernel_leg(fn, bytes_, reps=20):
+            for _ in range(3):
+                fn()
+            TCGNN.kernel_timing(*meta, max_calls=reps)
+            el = sync_time(fn, reps, 0, noop)
+            km = TCGNN.kernel_timing(*meta)
+            TCGNN.kernel_timing(*meta, max_calls=0)
+            kmean = float(np.mean(km))
+            return {"gteps": round(E / (el / reps) / 1e9, 3), "ms_per_call": round(el * 1e3 / reps, 4), "kernel_ms": round(kmean, 4),
+                    "hbm_frac": round(bytes_ / (kmean * 1e-3) / HBM_PEAK, 5)}
+        att = torch.randn(1, E, device=dev, generator=g)
+        extra["sddmm_d%d" % D] = kernel_leg(lambda: TCGNN.forward_ef(X, *meta), sddmm_bytes(n, E, D))
+        extra["spmm_agnn_d%d" % D] = kernel_leg(lambda: TCGNN.forward_AGNN(X, rp_d, col_d, att, bp, e2c, e2r), spmm_bytes(n, E, D) + 4 * E)
+        for d2 in (16, 128):
+            X2 = torch.randn(n, d2, device=dev, generator=g)
+            extra["spmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward(X2, *meta), spmm_bytes(n, E, d2), reps=10)
+            extra["sddmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward_ef(X2, *meta), sddmm_bytes(n, E, d2), reps=10)
+            del X2
+        del att
+        # ---- end-to-end epochs (main_tcgnn.py:146-181): 2 layers, hidden = D, 9 warm-up epochs
+        feats = torch.randn(n, in_dim, device=dev, generator=g)
+        labels = torch.ones(n, dtype=torch.long, device=dev)
+        for model in ("gcn", "agnn"):
+            r = H.time_training(model, meta, feats, labels, in_dim, D, classes, 2, args.epochs, seed=args.seed)
+            extra["%s_ms_per_epoch" % model] = round(r["train_ms"], 3)
+            extra["%s_final_loss_finite" % model] = bool(np.isfinite(r["final_loss"]))
+        del feats
+
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(rp_h.numpy(), col_h.numpy(), n, E, D, args.seed)
+    out["extra"] = extra
+    return out
+
+
+def cpu_baseline(rp, col, n, E, D, seed):
+    """oracle_csr_spmm on the host cores, bounded to roughly 10-30 s of CPU work."""
+    from oracle import oracle as O
+    threads = os.cpu_count() or 1
+    X = np.random.default_rng(seed).standard_normal((n, D)).astype(np.float32)
+    Y = np.empty((n, D), dtype=np.float32)
+    t0 = time.perf_counter(); O.csr_spmm(X, rp, col, threads=threads, out=Y); first = time.perf_counter() - t0   # warm-up + cost probe
+    reps = int(max(1, min(10, 15.0 / max(first, 1e-3))))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); O.csr_spmm(X, rp, col, threads=threads, out=Y); times.append(time.perf_counter() - t0)
+    best, mean = min(times), float(np.mean(times))
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    return {"value": round(E / mean / 1e9, 4), "unit": "GTEPS (SpMM, edges/s/1e9)", "cores": threads, "kind": "port",
+            "sample": "full %d-edge graph, D=%d, %d timed passes after 1 warm-up (mean %.3f s, min %.3f s)" % (E, D, reps, mean, best),
+            "what": "oracle_csr_spmm: row-parallel CSR gather-add, OpenMP, fp32 (DGL-CPU-style aggregation)", "cpu_model": cpu}
+
+
+def multi_gpu(args):
+    import tcgnn_graph as G
+    import tcgnn_shard as S
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    n0, nnz0, _, _ = G.SHAPES[args.shape]
+    if args.scale != 1.0:
+        n0, nnz0 = int(n0 * args.scale), int(nnz0 * args.scale * args.scale)
+    D = args.dim
+    n_global = n0 * world
+    # this rank's rows only: n0 rows, ~nnz0 edges, columns uniform over all n_global nodes
+    g = torch.Generator(device=dev).manual_seed(args.seed * 1000 + rank)
+    rows = torch.randint(0, n0, (nnz0,), device=dev, generator=g)
+    cols = torch.randint(0, n_global, (nnz0,), device=dev, generator=g)
+    keys = torch.unique(rows.long() * n_global + cols.long())
+    rows, cols = keys // n_global, keys % n_global
+    counts = torch.bincount(rows, minlength=n0)
+    lrp = torch.zeros(n0 + 1, dtype=torch.int64, device=dev); lrp[1:] = torch.cumsum(counts, 0)
+    E_local = int(keys.numel())
+    bounds = [p * n0 for p in range(world + 1)]
+    shard = S.RowShard(rank=rank, world_size=world, device=dev, bounds=bounds,
+                       local=(lrp.cpu().numpy().astype(np.int32), cols.cpu().numpy()))
+    del rows, cols, keys
+    x_local = torch.randn(n0, D, device=dev, generator=g)
+    step = lambda: shard.spmm(x_local)
+    barrier = lambda: dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    shard.ops.set_timing(args.steps)
+    elapsed = sync_time(step, args.steps, 0, barrier)
+    kernel_ms = shard.ops.read_timing()
+    # exchange-free time of the same step (X already gathered) for the exchange fraction
+    xg = shard.gather(x_local)
+    t_nox = sync_time(lambda: shard.ops.spmm(xg), args.steps, 2, barrier)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+    mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    out = None
+    if rank == 0:
+        t, t_local = float(mx[0]), float(mx[1])
+        E_total = float(sm[2])
+        k_mean = float(mx[3])
+        roof_b = spmm_bytes(n0, E_local, D) + 4 * (n_global - n0) * D  # + the remote X rows it must read once
+        out = {
+            "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
+            "value": round(E_total * args.steps / t / 1e9, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(t * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 operands (TF32-equivalent rounding), f32 accumulate, f32 I/O", "data": "synthetic",
+            "config": {"workload": "row-sharded %s-shape graph: %d nodes total, %d rows and ~%d nnz per GPU, SpMM D=%d, X all-gathered per step"
+                                   % (args.shape, n_global, n0, E_local, D), "parallelism": "row-window sharding x%d, RCCL all_gather_into_tensor of X" % world},
+            "roofline": {"bound": "hbm", "kernel": "spmm_kernel (slowest rank)", "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": None, "algorithmic_bytes": roof_b,
+                         "kernel_ms_mean": round(k_mean, 4)},
+            "extra": {"ms_per_step_without_exchange": round(t_local * 1e3 / args.steps, 4),
+                      "exchange_fraction": round(max(0.0, 1.0 - t_local / t), 4), "gathered_X_bytes_per_step": int(shard.layout.num_cols) * D * 4},
+        }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        if world == 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        out = multi_gpu(args)
+    else:
+        out = single_gpu(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

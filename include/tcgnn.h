@@ -107,8 +107,25 @@ int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
                       const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
                       const int32_t* d_edgeToRow, int32_t num_nodes, int64_t num_edges,
                       int32_t num_windows, void* stream, tcgnn_plan** plan_out);
+/* Row-sharded variant for multi-GPU runs (no counterpart in the reference, which is single-GPU):
+ * A holds `num_rows` rows (this rank's row windows; nodePointer has num_rows + 1 entries) whose
+ * column ids index a feature matrix of `num_cols` rows (the all-gathered X); A's row r is X's row
+ * row_offset + r (used by SDDMM).  X passed to the kernels is [num_cols, D], Y is [num_rows, D]. */
+int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edgeList,
+                              const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
+                              const int32_t* d_edgeToRow, int32_t num_rows, int32_t num_cols,
+                              int32_t row_offset, int64_t num_edges, int32_t num_windows,
+                              void* stream, tcgnn_plan** plan_out);
 int tcgnn_plan_destroy(tcgnn_plan* plan);
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
+
+/* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While
+ * enabled, tcgnn_spmm / tcgnn_spmm_val / tcgnn_sddmm bracket their main kernel (not the fp16
+ * staging pass) with events recorded on the caller's stream, without synchronising.
+ * tcgnn_plan_read_timing waits for the recorded calls, returns their durations in milliseconds
+ * (call order) and rearms the pairs. */
+int tcgnn_plan_set_timing(tcgnn_plan* plan, int32_t max_calls);
+int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, int32_t* count);
 
 /* Scratch bytes the three kernels need for feature width D (fp16 staging copy of X with one
  * zero sentinel row, plus the scale words).  The caller owns the scratch; it must be 256-byte

@@ -32,7 +32,7 @@ import torch
 import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
-           "plan_info", "clear_plan_cache"]
+           "plan_info", "kernel_timing", "clear_plan_cache"]
 
 _PLAN_CACHE_SIZE = 8
 _plans = collections.OrderedDict()  # key -> (handle, tensors kept alive)
@@ -118,11 +118,25 @@ def plan_info(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
     return {f: getattr(info, f) for f, _ in info._fields_}
 
 
+def kernel_timing(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, max_calls=None):
+    """Not part of the reference API.  kernel_timing(meta..., max_calls=K) arms HIP-event timing of
+    the main kernel for the next K calls on this graph; kernel_timing(meta...) (no max_calls) waits
+    for them and returns their durations in ms."""
+    plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    if max_calls is not None:
+        _c.check(_c.lib.tcgnn_plan_set_timing(plan, int(max_calls)), "tcgnn_plan_set_timing")
+        return None
+    buf = (_c.ctypes.c_float * 4096)()
+    n = _c._i32(0)
+    _c.check(_c.lib.tcgnn_plan_read_timing(plan, buf, 4096, _c.ctypes.byref(n)), "tcgnn_plan_read_timing")
+    return [buf[i] for i in range(n.value)]
+
+
 def _workspace(plan, D, device):
     need = _c.lib.tcgnn_workspace_bytes(plan, D)
     key = (device.index, _stream_handle(device))
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
+    if ws is None or ws.numel() < need + 256:
         ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     off = (-ws.data_ptr()) % 256

@@ -51,7 +51,9 @@ typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_raw;
     } while (0)
 
 struct tcgnn_plan {
-    int32_t N = 0, nw = 0, nw_eff = 0;
+    int32_t N = 0, nw = 0, nw_eff = 0;   // N: rows of A (= rows of Y)
+    int32_t Nc = 0;                      // columns of A = rows of X (== N unless row-sharded)
+    int32_t row_off = 0;                 // X row holding A's row 0 (row-sharded SDDMM)
     int64_t E = 0, tc_blocks = 0, total_wb = 0;
     int canonical = 0, waves = 1;
     const int32_t *rowptr = nullptr, *col = nullptr, *bp = nullptr, *e2c = nullptr, *e2r = nullptr; // borrowed
@@ -61,6 +63,19 @@ struct tcgnn_plan {
     uint32_t* d_mask = nullptr;   // [total_wb][16] bit c of word r: A[r][c] != 0
     int32_t* d_ebase = nullptr;   // [total_wb][16] CSR position of the first edge of row r in the tile
     size_t bytes = 0;
+    // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
+    mutable std::vector<hipEvent_t> ev;
+    mutable int ev_used = 0;
+};
+
+// Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
+// stream it is launched on, when timing is enabled and a pair is free.
+struct KernelTimer {
+    const tcgnn_plan* p; hipStream_t s; int slot = -1;
+    KernelTimer(const tcgnn_plan* plan, hipStream_t stream) : p(plan), s(stream) {
+        if (p && !p->ev.empty() && 2 * p->ev_used + 1 < (int)p->ev.size()) { slot = p->ev_used++; (void)hipEventRecord(p->ev[2 * slot], s); }
+    }
+    ~KernelTimer() { if (slot >= 0) (void)hipEventRecord(p->ev[2 * slot + 1], s); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -143,14 +158,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
                                                    const int32_t* __restrict__ e2c,
                                                    const int32_t* __restrict__ e2r,
                                                    const int64_t* __restrict__ wb_ptr, int32_t N,
-                                                   int32_t* cols, uint32_t* mask, int32_t* ebase,
-                                                   int32_t* flags) {
+                                                   int32_t Nc, int32_t* cols, uint32_t* mask,
+                                                   int32_t* ebase, int32_t* flags) {
     const int w = blockIdx.x;
     const int64_t n0 = (int64_t)w * kWinRows;
     const int64_t n1 = n0 + kWinRows < N ? n0 + kWinRows : N;
     const int64_t base = wb_ptr[w];
     const int64_t nwb = wb_ptr[w + 1] - base;
-    for (int64_t k = threadIdx.x; k < nwb * kWbCols; k += blockDim.x) cols[base * kWbCols + k] = N;
+    for (int64_t k = threadIdx.x; k < nwb * kWbCols; k += blockDim.x) cols[base * kWbCols + k] = Nc; // zero sentinel row
     for (int64_t k = threadIdx.x; k < nwb * kWinRows; k += blockDim.x) {
         mask[base * kWinRows + k] = 0u;
         ebase[base * kWinRows + k] = 0;
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
         const int c = e2c[e];
         const int r = e2r[e] - (int)n0;
         const int v = col[e];
-        if (c < 0 || (int64_t)c >= nwb * kWbCols || r < 0 || r >= kWinRows || v < 0 || v >= N) {
+        if (c < 0 || (int64_t)c >= nwb * kWbCols || r < 0 || r >= kWinRows || v < 0 || v >= Nc) {
             flags[0] = 1;
             continue;
         }
@@ -386,7 +401,7 @@ struct SddmmArgs {
     const _Float16* x16;
     const uint32_t* hdr;
     float* ef;
-    int32_t N, Dpad, stride;
+    int32_t N, Nc, row_off, Dpad, stride;
 };
 
 // KS = number of 32-wide k steps held in registers for the window rows (0: loop at run time and
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
 
     // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
     int64_t arow = (int64_t)w * kWinRows + i;
-    if (arow > a.N) arow = a.N;
+    arow = arow < a.N ? arow + a.row_off : a.Nc;
     const _Float16* ap = a.x16 + arow * stride + 8 * g;
     half8 af[KS > 0 ? KS : 1];
     if constexpr (KS > 0) {
@@ -476,11 +491,11 @@ __global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __rest
 __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col,
                                                         const float* __restrict__ X, float* ef,
-                                                        int32_t N, int32_t D) {
+                                                        int32_t N, int32_t D, int32_t row_off) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
-    const float* xr = X + row * D;
+    const float* xr = X + (row + row_off) * D;
     for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
         const float* xc = X + (int64_t)col[e] * D;
         float s = 0.f;
@@ -547,14 +562,14 @@ static size_t workspace_bytes_for(int32_t N, int32_t D) {
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
                           const _Float16** x16_out, int* dpad_out) {
-    const size_t need = workspace_bytes_for(plan->N, D);
+    const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
     uint32_t* hdr = static_cast<uint32_t*>(ws);
     _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
     const int dpad = round_up(D, 16);
     HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
-    const int64_t nx = (int64_t)plan->N * D;
+    const int64_t nx = (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(2048, (nx / 4 + 255) / 256 + 1);
         hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
@@ -563,11 +578,11 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
         const int grid = (int)std::min<int64_t>(2048, (plan->E / 4 + 255) / 256 + 1);
         hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1);
     }
-    const int64_t chunks = ((int64_t)plan->N + 1) * (dpad / 8);
+    const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
-    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->N, D, dpad, x16, hdr);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->N, D, dpad, x16, hdr);
+    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, x16, hdr);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, x16, hdr);
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad;
     return TCGNN_OK;
@@ -592,6 +607,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     if (plan->nw_eff == 0) return TCGNN_OK;
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, dpad, 0};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
+    KernelTimer timer(plan, stream);
     if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, 8, a, plan->nw_eff, nfull, stream)); }
     if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, rem, a, plan->nw_eff, 1, stream)); }
     return TCGNN_OK;
@@ -606,23 +622,28 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase);
+    for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
 }
 
-int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
-                      const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
-                      const int32_t* d_edgeToRow, int32_t num_nodes, int64_t num_edges,
-                      int32_t num_windows, void* stream_v, tcgnn_plan** plan_out) {
+int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edgeList,
+                              const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
+                              const int32_t* d_edgeToRow, int32_t num_rows, int32_t num_cols,
+                              int32_t row_offset, int64_t num_edges, int32_t num_windows,
+                              void* stream_v, tcgnn_plan** plan_out) {
     if (!plan_out) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_create: plan_out is null");
     *plan_out = nullptr;
+    const int32_t num_nodes = num_rows;
+    if (num_cols < 0 || row_offset < 0 || (int64_t)row_offset + num_rows > (int64_t)num_cols)
+        return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_create: rows [%d, %d) do not fit in %d feature rows", row_offset, row_offset + num_rows, num_cols);
     if (num_nodes < 0 || num_edges < 0 || num_windows < 0 || !d_nodePointer ||
         (num_windows > 0 && !d_blockPartition) || (num_edges > 0 && (!d_edgeList || !d_edgeToColumn || !d_edgeToRow)))
         return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_create: null array or negative size");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     tcgnn_plan* p = new (std::nothrow) tcgnn_plan();
     if (!p) return fail(TCGNN_ERR_OOM, "tcgnn_plan_create: host allocation failed");
-    p->N = num_nodes; p->E = num_edges; p->nw = num_windows;
+    p->N = num_nodes; p->Nc = num_cols; p->row_off = row_offset; p->E = num_edges; p->nw = num_windows;
     p->nw_eff = (int32_t)std::min<int64_t>(num_windows, ((int64_t)num_nodes + kWinRows - 1) / kWinRows);
     p->rowptr = d_nodePointer; p->col = d_edgeList; p->bp = d_blockPartition; p->e2c = d_edgeToColumn; p->e2r = d_edgeToRow;
     const int nw = p->nw_eff;
@@ -663,7 +684,7 @@ int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
     if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), stream);
     if (e == hipSuccess && nw > 0) {
         hipLaunchKernelGGL(pack_kernel, dim3((unsigned)nw), dim3(256), 0, stream, d_nodePointer, d_edgeList, d_edgeToColumn,
-                           d_edgeToRow, p->d_wb_ptr, num_nodes, p->d_cols, p->d_mask, p->d_ebase, d_flags);
+                           d_edgeToRow, p->d_wb_ptr, num_rows, num_cols, p->d_cols, p->d_mask, p->d_ebase, d_flags);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, stream);
@@ -676,6 +697,14 @@ int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
     return TCGNN_OK;
 }
 
+int tcgnn_plan_create(const int32_t* d_nodePointer, const int32_t* d_edgeList,
+                      const int32_t* d_blockPartition, const int32_t* d_edgeToColumn,
+                      const int32_t* d_edgeToRow, int32_t num_nodes, int64_t num_edges,
+                      int32_t num_windows, void* stream, tcgnn_plan** plan_out) {
+    return tcgnn_plan_create_sharded(d_nodePointer, d_edgeList, d_blockPartition, d_edgeToColumn, d_edgeToRow, num_nodes,
+                                     num_nodes, 0, num_edges, num_windows, stream, plan_out);
+}
+
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     if (!plan || !info) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_get_info: null argument");
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
@@ -684,9 +713,35 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     return TCGNN_OK;
 }
 
+int tcgnn_plan_set_timing(tcgnn_plan* plan, int32_t max_calls) {
+    if (!plan || max_calls < 0) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_timing: bad argument");
+    for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
+    plan->ev.clear();
+    plan->ev_used = 0;
+    for (int i = 0; i < 2 * max_calls; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        plan->ev.push_back(e);
+    }
+    return TCGNN_OK;
+}
+
+int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, int32_t* count) {
+    if (!plan || !count || (capacity > 0 && !ms_out)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_read_timing: null argument");
+    int n = 0;
+    for (int i = 0; i < plan->ev_used && n < capacity; ++i) {
+        HIP_TRY(hipEventSynchronize(plan->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[n], plan->ev[2 * i], plan->ev[2 * i + 1]));
+        ++n;
+    }
+    *count = n;
+    plan->ev_used = 0;
+    return TCGNN_OK;
+}
+
 size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     if (!plan || D < 1) return 0;
-    return workspace_bytes_for(plan->N, D);
+    return workspace_bytes_for(plan->Nc, D);
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
@@ -704,7 +759,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->E == 0 || plan->N == 0) return TCGNN_OK;
     if (!plan->canonical) {
-        hipLaunchKernelGGL(sddmm_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream, plan->rowptr, plan->col, d_X, d_ef, plan->N, D);
+        hipLaunchKernelGGL(sddmm_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream, plan->rowptr, plan->col, d_X, d_ef, plan->N, D, plan->row_off);
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     }
@@ -712,8 +767,9 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const uint32_t* hdr; const _Float16* x16; int dpad;
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, dpad, dpad};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, dpad};
     const int ks = (dpad + 31) / 32;
+    KernelTimer timer(plan, stream);
     hipError_t e = plan->waves == 4 ? launch_sddmm_ks<4>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1>(ks, a, plan->nw_eff, stream);
     HIP_TRY(e);
     return TCGNN_OK;

@@ -121,6 +121,10 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
                      int64_t* tc_blocks, int32_t num_threads) {
     if (!nodePointer || num_nodes < 0 || blockSize_h <= 0 || blockSize_w <= 0 || bp_len < 0)
         return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_preprocess: bad sizes (N=%d, bh=%d, bw=%d)", num_nodes, blockSize_h, blockSize_w);
+    if (nodePointer[0] < 0) return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_preprocess: nodePointer[0] = %d is negative", nodePointer[0]);
+    for (int32_t r = 0; r < num_nodes; ++r)
+        if (nodePointer[r + 1] < nodePointer[r])
+            return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_preprocess: nodePointer decreases at row %d (%d -> %d)", r, nodePointer[r], nodePointer[r + 1]);
     const int64_t E = nodePointer[num_nodes];
     if (E < 0 || (E > 0 && (!edgeList || !edgeToColumn || !edgeToRow)) || (bp_len > 0 && !blockPartition))
         return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_preprocess: null array");
@@ -133,7 +137,6 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
 
     std::atomic<int64_t> next{0};
     std::atomic<int64_t> total{0};
-    std::atomic<int> bad{0};
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, visited / (nthreads * 8) + 1));
 
     auto worker = [&]() {
@@ -150,10 +153,7 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
                     for (int64_t e = nodePointer[r]; e < nodePointer[r + 1]; ++e) edgeToRow[e] = (int32_t)r;
                 bool rows_sorted = true;
                 uint32_t uniq = 0;
-                if (n0 < n1) {
-                    if (nodePointer[n1] < nodePointer[n0]) { bad.store(1); continue; }
-                    uniq = window_unique(edgeList, nodePointer, n0, n1, s, &rows_sorted);
-                }
+                if (n0 < n1) uniq = window_unique(edgeList, nodePointer, n0, n1, s, &rows_sorted);
                 const uint32_t* U = s.a.data();
                 if (uniq) {
                     if (rows_sorted) {
@@ -189,7 +189,6 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
         for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
         for (auto& t : pool) t.join();
     }
-    if (bad.load()) return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_preprocess: nodePointer is not non-decreasing");
     if (tc_blocks) *tc_blocks = total.load();
     return TCGNN_OK;
 }

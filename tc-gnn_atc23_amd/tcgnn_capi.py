@@ -35,8 +35,11 @@ SIGNATURES = {
     "tcgnn_preprocess": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _i32]),
     "tcgnn_preprocess_gpu": (ctypes.c_int, [_i32p, _i32p, _i32, _i64, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _vp]),
     "tcgnn_plan_create": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
+    "tcgnn_plan_create_sharded": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i32, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_destroy": (ctypes.c_int, [_vp]),
     "tcgnn_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfo)]),
+    "tcgnn_plan_set_timing": (ctypes.c_int, [_vp, _i32]),
+    "tcgnn_plan_read_timing": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), _i32, ctypes.POINTER(_i32)]),
     "tcgnn_workspace_bytes": (_sz, [_vp, _i32]),
     "tcgnn_spmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_spmm_val": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),

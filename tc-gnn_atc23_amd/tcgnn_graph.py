@@ -1,0 +1,124 @@
+"""Graph ingestion for the TC-GNN path - the host-side mirror of the reference's dataset.py.
+
+`TCGNN_dataset(path, dim, num_class, load_from_txt)` accepts the same inputs as dataset.py:13-122:
+an .npz with `src_li`, `dst_li`, `num_nodes` (dataset.py:74-80) or a whitespace edge list, and
+exposes the same attributes (`num_nodes`, `num_edges`, `num_features`, `num_classes`,
+`column_index`, `row_pointers`, `x`, `y`, `degrees`).  Facts reproduced on purpose, pinned by
+tests/golden/dataset_toy.npz:
+  * the CSR is scipy's canonical form (duplicates merged, columns sorted): dataset.py:94-104,
+  * `num_edges` is the RAW pair count, so it can exceed nnz (dataset.py:79); the metadata tensors
+    main_tcgnn.py allocates from it (main_tcgnn.py:45-46) are then longer than column_index,
+  * features are randn(N, dim), labels all ones (dataset.py:115,122).
+Unlike the reference nothing is moved to the GPU behind the caller's back; call `.to(device)`.
+
+Also here: seeded synthetic generators for the shapes BASELINE.json names (no datasets and no
+network exist on either box), built with torch so the Reddit-sized graph can be made on the GPU.
+"""
+import numpy as np
+import torch
+from scipy.sparse import coo_matrix
+
+
+def _func(x):  # config.py:5-9: degree clamp
+    return x if x > 0 else 1
+
+
+class TCGNN_dataset(torch.nn.Module):
+    def __init__(self, path, dim, num_class, load_from_txt=True, verbose=False, seed=None):
+        super().__init__()
+        self.num_features = dim
+        self.num_classes = num_class
+        self.verbose_flag = verbose
+        if load_from_txt:
+            pairs = np.loadtxt(path, dtype=np.int64, ndmin=2)
+            src, dst = pairs[:, 0], pairs[:, 1]
+            self.num_nodes = int(max(src.max(), dst.max())) + 1 if len(src) else 0
+        else:
+            if not str(path).endswith(".npz"):
+                raise ValueError("graph file must be a .npz file")
+            obj = np.load(path)
+            src, dst = obj["src_li"], obj["dst_li"]
+            self.num_nodes = int(obj["num_nodes"])
+        self.num_edges = len(src)  # raw count, before duplicates are merged
+        self.edge_index = np.stack([src, dst])
+        self.avg_degree = self.num_edges / max(self.num_nodes, 1)
+        self.avg_edgeSpan = float(np.mean(np.abs(np.subtract(src, dst)))) if len(src) else 0.0
+        csr = coo_matrix((np.ones(self.num_edges, dtype=np.int64), self.edge_index),
+                         shape=(self.num_nodes, self.num_nodes)).tocsr()
+        csr.sum_duplicates()
+        csr.sort_indices()
+        self.column_index = torch.from_numpy(csr.indices.astype(np.int32))
+        self.row_pointers = torch.from_numpy(csr.indptr.astype(np.int32))
+        deg = (self.row_pointers[1:] - self.row_pointers[:-1]).clamp(min=1).float()
+        self.degrees = torch.sqrt(deg)
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        self.x = torch.randn(self.num_nodes, dim, generator=gen)
+        self.y = torch.ones(self.num_nodes).long()
+        if verbose:
+            print("# nodes: {}".format(self.num_nodes))
+            print("# avg_degree: {:.2f}".format(self.avg_degree))
+            print("# avg_edgeSpan: {}".format(int(self.avg_edgeSpan)))
+
+    def to(self, device):
+        for name in ("column_index", "row_pointers", "degrees", "x", "y"):
+            setattr(self, name, getattr(self, name).to(device))
+        return self
+
+
+# ---------------------------------------------------------------- synthetic shapes
+
+SHAPES = {  # name: (N, nnz target, in_dim, classes) - SURVEY.md 8(d)
+    "cora": (2708, 10556, 1433, 7),
+    "citeseer": (3327, 9228, 3703, 6),
+    "pubmed": (19717, 88648, 500, 3),
+    "reddit": (232965, 114615892, 602, 41),
+    "ogbn-products": (2449029, 123718280, 100, 47),
+}
+
+
+def synthetic_csr(num_nodes, nnz_target, seed=0, device="cpu", skew=0.0):
+    """Seeded symmetric graph without self loops, canonical CSR, nnz within ~0.1 % of the target.
+    skew = 0: uniform endpoints; skew > 0: one endpoint drawn as floor(N * u^(1+skew)) of a random
+    permutation (heavier tail).  Returns int32 (row_pointers, column_index) on `device`."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    n = int(num_nodes)
+    half = int(nnz_target) // 2
+    keys = torch.empty(0, dtype=torch.int64, device=dev)
+    want = half
+    for _ in range(6):  # top up what symmetrisation / dedup / self-loop removal ate
+        m = int(want * 1.002) + 16
+        u = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+        if skew > 0:
+            u = u ** (1.0 + skew)
+        a = (u * n).long().clamp_(max=n - 1)
+        b = torch.randint(0, n, (m,), generator=g, device=dev)
+        if skew > 0:
+            perm = torch.randperm(n, generator=g, device=dev)
+            a = perm[a]
+        lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+        keep = lo != hi
+        keys = torch.unique(torch.cat([keys, lo[keep] * n + hi[keep]]))
+        if keys.numel() >= half:
+            break
+        want = half - keys.numel()
+    if keys.numel() > half:
+        keys = keys[torch.randperm(keys.numel(), generator=g, device=dev)[:half]]
+    lo, hi = keys // n, keys % n
+    full = torch.sort(torch.cat([lo * n + hi, hi * n + lo]))[0]
+    rows, cols = full // n, (full % n).to(torch.int32)
+    counts = torch.bincount(rows, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr.to(torch.int32), cols.contiguous()
+
+
+def synthetic_shape(name, seed=0, device="cpu", scale=1.0):
+    """(row_pointers, column_index, in_dim, classes) for a named shape; `scale` shrinks N and nnz
+    together (tests use small scales)."""
+    n, nnz, dim, classes = SHAPES[name]
+    n2 = max(16, int(n * scale))
+    nnz2 = max(2, int(nnz * scale * scale)) if scale < 1.0 else nnz
+    nnz2 = min(nnz2, n2 * (n2 - 1) // 2)
+    rp, col = synthetic_csr(n2, nnz2, seed=seed, device=device)
+    return rp, col, dim, classes

@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Training / profiling harness - the host-side mirror of the reference's main_tcgnn.py.
+
+Same flags (main_tcgnn.py:18-27), same flow (load -> preprocess -> move metadata -> model ->
+9 warm-up + `--epochs` timed train steps, or `--single_kernel` SAG profile), same stdout lines
+(`Prep. (ms):\\t%.3f`, `Train (ms):\\t%6.3f`, `=> SAG profiling avg (ms): %.3f`), so the reference's
+1_bench_gcn.py / 2_tcgnn_single_kernel.py / 1_log2csv.py drive and scrape it unchanged.
+
+Additions: `--synthetic <shape>` builds a seeded graph of a named shape (no dataset files exist on
+the GPU box), `--graph_dir` relocates tcgnn-ae-graphs/, `--gpu_preprocess` uses the device SGT.
+`run(args)` returns the measured numbers so bench.py and the tests can call it in-process.
+"""
+import argparse
+import os.path as osp
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BLK_H, BLK_W = 16, 8  # config.py:1-2
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset", type=str, default="amazon0601", help="dataset")
+    p.add_argument("--dim", type=int, default=96, help="input embedding dimension")
+    p.add_argument("--num_layers", type=int, default=2, help="num layers")
+    p.add_argument("--hidden", type=int, default=16, help="hidden dimension")
+    p.add_argument("--classes", type=int, default=22, help="number of output classes")
+    p.add_argument("--epochs", type=int, default=200, help="number of epoches")
+    p.add_argument("--model", type=str, default="gcn", help="GNN model", choices=["gcn", "gin", "agnn"])
+    p.add_argument("--single_kernel", action="store_true", help="whether to profile a single SAG kernel")
+    p.add_argument("--synthetic", type=str, default=None, help="named synthetic shape instead of a dataset file")
+    p.add_argument("--scale", type=float, default=1.0, help="shrink a synthetic shape (N*scale, nnz*scale^2)")
+    p.add_argument("--graph_dir", type=str, default="tcgnn-ae-graphs/")
+    p.add_argument("--gpu_preprocess", action="store_true", help="run the sparse-graph translation on the GPU")
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+class Net(nn.Module):
+    """conv1 -> relu -> dropout -> [hidden convs + relu] -> conv2 -> log_softmax (main_tcgnn.py:75-139)."""
+
+    def __init__(self, conv_cls, in_dim, hidden, classes, num_layers):
+        super().__init__()
+        self.conv1 = conv_cls(in_dim, hidden)
+        self.hidden_layers = nn.ModuleList(conv_cls(hidden, hidden) for _ in range(num_layers - 2))
+        self.conv2 = conv_cls(hidden, classes)
+        self.relu = nn.ReLU()
+
+    def forward(self, x, meta):
+        x = self.relu(self.conv1(x, *meta))
+        x = F.dropout(x, training=self.training)
+        for conv in self.hidden_layers:
+            x = self.relu(conv(x, *meta))
+        x = self.conv2(x, *meta)
+        return F.log_softmax(x, dim=1)
+
+
+def load_graph(args):
+    import tcgnn_graph as G
+    if args.synthetic:
+        rp, col, dim, classes = G.synthetic_shape(args.synthetic, seed=args.seed, scale=args.scale,
+                                                   device="cuda" if torch.cuda.is_available() else "cpu")
+        n = rp.numel() - 1
+        gen = torch.Generator().manual_seed(args.seed)
+        ds = argparse.Namespace(num_nodes=n, num_edges=col.numel(), column_index=col.cpu(), row_pointers=rp.cpu(),
+                                num_features=args.dim, num_classes=args.classes,
+                                x=torch.randn(n, args.dim, generator=gen), y=torch.ones(n).long())
+        return ds
+    path = osp.join(args.graph_dir, args.dataset + ".npz")
+    return G.TCGNN_dataset(path, args.dim, args.classes, load_from_txt=False, seed=args.seed)
+
+
+def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9):
+    """The timed part of main_tcgnn.py (:141-181) on tensors that already live on the GPU:
+    Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones."""
+    import tcgnn_layers as L
+    conv_cls = {"gcn": L.GCNConv, "gin": L.GINConv, "agnn": L.AGNNConv}[model_name]
+    torch.manual_seed(seed)
+    model = Net(conv_cls, in_dim, hidden, classes, num_layers).to(x.device)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+
+    def train():
+        model.train()
+        optimizer.zero_grad()
+        loss = F.nll_loss(model(x, meta), y)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for _ in range(warmup):
+        train()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(epochs):
+        loss = train()
+    torch.cuda.synchronize()
+    return {"train_ms": (time.perf_counter() - start) * 1e3 / max(epochs, 1), "final_loss": float(loss)}
+
+
+def run(args, quiet=False):
+    import TCGNN
+    import tcgnn_layers as L
+    say = (lambda *a, **k: None) if quiet else print
+    say(args)
+    device = torch.device("cuda:0")
+    ds = load_graph(args)
+    num_nodes, num_edges = ds.num_nodes, ds.num_edges
+    column_index, row_pointers = ds.column_index, ds.row_pointers
+
+    # metadata allocated exactly as main_tcgnn.py:44-47 does (edge arrays sized by the RAW edge count)
+    num_row_windows = (num_nodes + BLK_H - 1) // BLK_H
+    edgeToColumn = torch.zeros(num_edges, dtype=torch.int)
+    edgeToRow = torch.zeros(num_edges, dtype=torch.int)
+    blockPartition = torch.zeros(num_row_windows, dtype=torch.int)
+
+    start = time.perf_counter()
+    if args.gpu_preprocess:
+        column_index, row_pointers = column_index.to(device), row_pointers.to(device)
+        blockPartition, edgeToColumn, edgeToRow = blockPartition.to(device), edgeToColumn.to(device), edgeToRow.to(device)
+        TCGNN.preprocess_gpu(column_index, row_pointers, num_nodes, BLK_H, BLK_W, blockPartition, edgeToColumn, edgeToRow)
+        torch.cuda.synchronize()
+    else:
+        TCGNN.preprocess(column_index, row_pointers, num_nodes, BLK_H, BLK_W, blockPartition, edgeToColumn, edgeToRow)
+    prep_ms = (time.perf_counter() - start) * 1e3
+    say("Prep. (ms):\t{:.3f}".format(prep_ms))
+
+    meta = tuple(t.to(device) for t in (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow))
+    x, y = ds.x.to(device), ds.y.to(device)
+    result = {"prep_ms": prep_ms, "num_nodes": num_nodes, "nnz": int(column_index.numel())}
+
+    if args.single_kernel:
+        result["sag_ms"] = L.SAG(*meta).profile(x)
+        return result
+
+    r = time_training(args.model, meta, x, y, ds.num_features, args.hidden, ds.num_classes, args.num_layers, args.epochs,
+                      seed=args.seed, warmup=9)  # 9 dry epochs, main_tcgnn.py:166-167
+    say("Train (ms):\t{:6.3f}".format(r["train_ms"]))
+    result.update(r)
+    return result
+
+
+if __name__ == "__main__":
+    run(build_parser().parse_args())

@@ -1,0 +1,187 @@
+"""Layer library over the TCGNN operator API - the host-side mirror of the reference's gnn_conv.py.
+
+Same class names, constructor arguments, forward signatures and gradient formulas as
+gnn_conv.py:26-247, so a model written against the reference runs against this file:
+
+    TCGNNFunction_SAG   Y = A X                         bwd: dX = A dY                 (:26-49)
+    TCGNNFunction       Y = A (X W)                     bwd: G = A dY; dX = G W^T; dW = X^T G   (:52-85)
+    TCGNNFunction_GIN   Y = (A X) W                     bwd: dW = (A X)^T dY; dX = A (dY W^T)   (:87-113)
+    TCGNNFunction_AGNN  H = X W; ef = sddmm(H); att = (ef[:,None] @ a)^T; Y = A_att H         (:115-158)
+                        bwd: G = A_att dY; dX = G W^T; dW = X^T G;
+                             da = (sddmm(dY)[None,:] @ col[:,None].float())^T
+    SAG / GCNConv / GINConv / AGNNConv modules, n_heads = 1                                    (:10, :167-247)
+
+The reference's backward uses A, not A^T (it assumes a symmetric graph) and does not propagate
+through ef into H; both are reproduced because the golden fixtures captured from gnn_conv.py
+(tests/golden/layers_n200.npz) pin exactly that.
+
+The operators come from `backend()`: the TCGNN module of this package (HIP kernels).  Tests on a
+machine without a GPU may install another object with the same three functions via set_backend().
+"""
+import math
+import time
+
+import torch
+
+n_heads = 1  # gnn_conv.py:10
+
+_backend = None
+
+
+def set_backend(module):
+    global _backend
+    _backend = module
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        import TCGNN  # the drop-in extension module of this package; raises if the library is missing
+        _backend = TCGNN
+    return _backend
+
+
+class TCGNNFunction_SAG(torch.autograd.Function):
+    """Pure neighbour aggregation."""
+
+    @staticmethod
+    def forward(ctx, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        return backend().forward(X, *ctx.meta)[0]
+
+    @staticmethod
+    def backward(ctx, d_output):
+        d_input = backend().forward(d_output.contiguous(), *ctx.meta)[0]
+        return (d_input,) + (None,) * 5
+
+
+class TCGNNFunction(torch.autograd.Function):
+    """GCN layer: dense update first, aggregation second."""
+
+    @staticmethod
+    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        ctx.save_for_backward(X, weights)
+        return backend().forward(torch.mm(X, weights), *ctx.meta)[0]
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X, weights = ctx.saved_tensors
+        g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
+        return (torch.mm(g, weights.t()), torch.mm(X.t(), g)) + (None,) * 5
+
+
+class TCGNNFunction_GIN(torch.autograd.Function):
+    """GIN layer: aggregation first, dense update second."""
+
+    @staticmethod
+    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        agg = backend().forward(X, *ctx.meta)[0]
+        ctx.save_for_backward(agg, weights)
+        return torch.mm(agg, weights)
+
+    @staticmethod
+    def backward(ctx, d_output):
+        agg, weights = ctx.saved_tensors
+        d_agg = torch.mm(d_output, weights.t())
+        d_weights = torch.mm(agg.t(), d_output)
+        d_input = backend().forward(d_agg.contiguous(), *ctx.meta)[0]
+        return (d_input, d_weights) + (None,) * 5
+
+
+class TCGNNFunction_AGNN(torch.autograd.Function):
+    """AGNN layer: edge scores by SDDMM, then edge-weighted aggregation."""
+
+    @staticmethod
+    def forward(ctx, X, weights, attention_w, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        H = torch.mm(X, weights)
+        ef = backend().forward_ef(H, *meta)[0]
+        # reference: mm(ef[:, None], attention_w).T -> [n_heads, E]; a k = 1 matmul is one product per
+        # element, so the broadcast below is value-identical and avoids a degenerate GEMM launch
+        att = (attention_w.reshape(-1, 1) * ef.unsqueeze(0)).contiguous()
+        out = backend().forward_AGNN(H, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
+        ctx.meta = meta
+        ctx.save_for_backward(X, weights, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X, weights, att = ctx.saved_tensors
+        row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow = ctx.meta
+        d_output = d_output.contiguous()
+        g = backend().forward_AGNN(d_output, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
+        d_input = torch.mm(g, weights.t())
+        d_weights = torch.mm(X.t(), g)
+        d_att = backend().forward_ef(d_output, *ctx.meta)[0]
+        # reference: mm(d_att[None, :].expand(n_heads, -1), column_index[:, None].float()).T, i.e. the
+        # dot product <d_att, column_index> per head.  As an [n_heads, E] x [E] matrix-vector product:
+        # the 1 x E x 1 GEMM form falls off rocBLAS' fast paths at E ~ 1e8 (30 s per call measured).
+        d_attention_w = torch.mv(d_att[None, :].expand(n_heads, -1), column_index.float()).reshape(1, n_heads)
+        return (d_input, d_weights, d_attention_w) + (None,) * 5
+
+
+class SAG(torch.nn.Module):
+    """Holds the graph metadata; profile() times `num_rounds` bare aggregations (gnn_conv.py:179-190,
+    the single-kernel benchmark of 2_tcgnn_single_kernel.py) and prints the line 1_log2csv.py scrapes."""
+
+    def __init__(self, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        super().__init__()
+        self.row_pointers = row_pointers
+        self.column_index = column_index
+        self.blockPartition = blockPartition
+        self.edgeToColumn = edgeToColumn
+        self.edgeToRow = edgeToRow
+
+    def forward(self, X):
+        return TCGNNFunction_SAG.apply(X, self.row_pointers, self.column_index, self.blockPartition, self.edgeToColumn, self.edgeToRow)
+
+    def profile(self, X, num_rounds=200):
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in range(num_rounds):
+            self.forward(X)
+        torch.cuda.synchronize()
+        avg_ms = (time.perf_counter() - start) * 1e3 / num_rounds
+        print("=> SAG profiling avg (ms): {:.3f}".format(avg_ms))
+        print()
+        return avg_ms
+
+
+class GCNConv(torch.nn.Module):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.weights = torch.nn.Parameter(torch.randn(input_dim, output_dim))  # unscaled, as gnn_conv.py:195
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.weights.size(1))
+        self.weights.data.uniform_(-bound, bound)
+
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        return TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+
+
+class GINConv(torch.nn.Module):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.weights = torch.nn.Parameter(torch.randn(input_dim, output_dim))
+
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        return TCGNNFunction_GIN.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+
+
+class AGNNConv(torch.nn.Module):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.weights = torch.nn.Parameter(torch.randn(input_dim, output_dim))
+        self.attention_w = torch.nn.Parameter(torch.randn(1, n_heads))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.weights.size(1))
+        self.weights.data.uniform_(-bound, bound)
+
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        return TCGNNFunction_AGNN.apply(X, self.weights, self.attention_w, row_pointers, column_index, blockPartition,
+                                        edgeToColumn, edgeToRow)

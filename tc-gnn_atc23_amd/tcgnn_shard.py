@@ -1,0 +1,242 @@
+"""Row-window sharding of the aggregation path across the GPUs of one node (RCCL over xGMI).
+
+The reference is single-GPU (main_tcgnn.py:141 hard-codes cuda:0; no collective anywhere).  The
+multi-GPU form below is the one SURVEY.md 8(e) derives from the path itself:
+
+  * units = 16-row windows.  Rank p owns a contiguous block of windows, balanced by nnz
+    (`partition_rows`), i.e. the rows [b_p, b_{p+1}) of A, a local int32 CSR and local
+    blockPartition / edgeToColumn / edgeToRow (condensing is per window, so sharding never changes
+    them), and computes Y[b_p : b_{p+1}].
+  * the one real exchange step: SpMM needs every X row its columns reference, so X's row blocks are
+    all-gathered (`all_gather_into_tensor`, one process per GPU, backend "nccl" = RCCL).  xGMI is
+    point-to-point - each GPU pushes its block to its 7 peers at once - so the message is kept as
+    ONE large gather per SpMM, not bucketed.  Blocks are padded to a common height H so the gather
+    output IS the global matrix: global row id = rank * H + local row, and column ids are remapped
+    to that numbering once at set-up (no compaction copy per step).
+  * SDDMM shards the same way; ef stays sharded by edge range, no reduction.
+  * graphs that fit one GPU can replicate X and skip the exchange (`exchange=False`).
+  * backward of the aggregation uses A, not A^T, exactly like the reference's single-GPU layers
+    (gnn_conv.py:46,80: symmetric graphs), so it is the same gather + SpMM on dY.
+
+Operators come from a backend: `HipShardOps` (C ABI, tcgnn_plan_create_sharded) on GPUs, or any
+object with the same three methods - the gloo world_size-2 tests on CPU pass an oracle-backed one.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+BLK_H = 16
+
+
+def partition_rows(row_pointers, world_size):
+    """Boundaries b[0..world] (multiples of 16 except the last) splitting rows into contiguous
+    blocks of whole row windows with nnz as even as the windows allow."""
+    rp = np.asarray(row_pointers, dtype=np.int64)
+    n = len(rp) - 1
+    nw = (n + BLK_H - 1) // BLK_H
+    win_end = rp[np.minimum(np.arange(1, nw + 1) * BLK_H, n)]
+    total = rp[n]
+    bounds = [0]
+    for p in range(1, world_size):
+        target = total * p / world_size
+        w = int(np.searchsorted(win_end, target, side="left")) + 1
+        w = max(w, bounds[-1] // BLK_H)
+        w = min(w, nw)
+        bounds.append(min(w * BLK_H, n))
+    bounds.append(n)
+    return [int(b) for b in bounds]
+
+
+class ShardLayout:
+    """Numbering of the all-gathered feature matrix: rank p's rows live at [p*H, p*H + rows_p)."""
+
+    def __init__(self, bounds):
+        self.bounds = list(bounds)
+        self.world = len(bounds) - 1
+        rows = [bounds[p + 1] - bounds[p] for p in range(self.world)]
+        self.H = max(BLK_H, (max(rows) + BLK_H - 1) // BLK_H * BLK_H)
+        self.rows = rows
+        self.num_cols = self.H * self.world
+
+    def remap(self, global_ids):
+        g = np.asarray(global_ids, dtype=np.int64)
+        owner = np.searchsorted(np.asarray(self.bounds[1:], dtype=np.int64), g, side="right")
+        return (owner * self.H + (g - np.asarray(self.bounds, dtype=np.int64)[owner])).astype(np.int32)
+
+
+def local_csr(row_pointers, column_index, layout, rank):
+    """This rank's rows as a local CSR whose column ids use the gathered numbering."""
+    rp = np.asarray(row_pointers, dtype=np.int64)
+    b0, b1 = layout.bounds[rank], layout.bounds[rank + 1]
+    lrp = (rp[b0: b1 + 1] - rp[b0]).astype(np.int32)
+    cols = layout.remap(np.asarray(column_index)[rp[b0]: rp[b1]])
+    # remapping is monotone inside an owner block and blocks are ordered, so rows stay sorted
+    return lrp, cols
+
+
+class HipShardOps:
+    """The three kernels on this rank's row shard through the C ABI (GPU)."""
+
+    def __init__(self, lrp, lcol, layout, rank, device):
+        import tcgnn_capi as c
+        self.c, self.dev = c, device
+        self.rows, self.num_cols, self.row_off = len(lrp) - 1, layout.num_cols, rank * layout.H
+        n, nnz = self.rows, len(lcol)
+        nw = (n + BLK_H - 1) // BLK_H
+        bp = np.zeros(max(nw, 1), np.int32); e2c = np.zeros(max(nnz, 1), np.int32); e2r = np.zeros(max(nnz, 1), np.int32)
+        lrp = np.ascontiguousarray(lrp, np.int32); lcol = np.ascontiguousarray(lcol, np.int32)
+        c.check(c.lib.tcgnn_preprocess(lcol.ctypes.data, lrp.ctypes.data, n, 16, 8, bp.ctypes.data, nw, e2c.ctypes.data, e2r.ctypes.data, None, 0),
+                "tcgnn_preprocess")
+        self.meta = [torch.from_numpy(a).to(device) for a in (lrp, lcol, bp[:nw], e2c[:nnz], e2r[:nnz])]
+        self.nnz = nnz
+        self.plan = c._vp()
+        with torch.cuda.device(device):
+            st = c.lib.tcgnn_plan_create_sharded(*[t.data_ptr() for t in self.meta], n, self.num_cols, self.row_off, nnz, nw,
+                                                 torch.cuda.current_stream(device).cuda_stream, c.ctypes.byref(self.plan))
+        c.check(st, "tcgnn_plan_create_sharded")
+        self._ws = None
+
+    def _workspace(self, D):
+        need = self.c.lib.tcgnn_workspace_bytes(self.plan, D)
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.dev)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    def _check(self, Xg):
+        assert Xg.is_cuda and Xg.is_contiguous() and Xg.dtype == torch.float32 and Xg.shape[0] == self.num_cols
+
+    def spmm(self, Xg):
+        self._check(Xg)
+        D = Xg.shape[1]
+        Y = torch.empty(self.rows, D, device=self.dev)
+        ws, nb = self._workspace(D)
+        with torch.cuda.device(self.dev):
+            self.c.check(self.c.lib.tcgnn_spmm(self.plan, Xg.data_ptr(), Y.data_ptr(), D, ws, nb, torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_spmm")
+        return Y
+
+    def spmm_val(self, Xg, val):
+        self._check(Xg)
+        D = Xg.shape[1]
+        Y = torch.empty(self.rows, D, device=self.dev)
+        ws, nb = self._workspace(D)
+        with torch.cuda.device(self.dev):
+            self.c.check(self.c.lib.tcgnn_spmm_val(self.plan, Xg.data_ptr(), val.contiguous().data_ptr(), Y.data_ptr(), D, ws, nb,
+                                                   torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_spmm_val")
+        return Y
+
+    def sddmm(self, Xg):
+        self._check(Xg)
+        D = Xg.shape[1]
+        ef = torch.empty(self.nnz, device=self.dev)
+        ws, nb = self._workspace(D)
+        with torch.cuda.device(self.dev):
+            self.c.check(self.c.lib.tcgnn_sddmm(self.plan, Xg.data_ptr(), ef.data_ptr(), D, ws, nb, torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_sddmm")
+        return ef
+
+    def set_timing(self, max_calls):
+        self.c.check(self.c.lib.tcgnn_plan_set_timing(self.plan, int(max_calls)), "tcgnn_plan_set_timing")
+
+    def read_timing(self):
+        buf = (self.c.ctypes.c_float * 4096)()
+        n = self.c._i32(0)
+        self.c.check(self.c.lib.tcgnn_plan_read_timing(self.plan, buf, 4096, self.c.ctypes.byref(n)), "tcgnn_plan_read_timing")
+        return [buf[i] for i in range(n.value)]
+
+    def close(self):
+        if self.plan:
+            torch.cuda.synchronize(self.dev)
+            self.c.lib.tcgnn_plan_destroy(self.plan)
+            self.plan = None
+
+
+class _GatherSpmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, shard):
+        ctx.shard = shard
+        return shard.ops.spmm(shard.gather(x_local))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        shard = ctx.shard  # A, not A^T: the reference's symmetric-graph convention (gnn_conv.py:46)
+        return shard.ops.spmm(shard.gather(d_out.contiguous())), None
+
+
+class RowShard:
+    """One rank's share of a graph plus the exchange step."""
+
+    def __init__(self, row_pointers=None, column_index=None, rank=None, world_size=None, device=None, group=None,
+                 ops_factory=None, bounds=None, local=None):
+        """Either the whole CSR (row_pointers, column_index; every rank holds it or builds it the
+        same way) or `local=(local_row_pointers, global_column_ids)` + `bounds` when each rank only
+        ever materialises its own rows (graphs too large for one host/GPU)."""
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world_size is None else world_size
+        self.device = device if device is not None else torch.device("cpu")
+        if local is not None:
+            assert bounds is not None, "local shards need the global row boundaries"
+            self.layout = ShardLayout(bounds)
+            lrp = np.ascontiguousarray(local[0], dtype=np.int32)
+            lcol = self.layout.remap(local[1])
+        else:
+            bounds = bounds if bounds is not None else partition_rows(row_pointers, self.world)
+            self.layout = ShardLayout(bounds)
+            lrp, lcol = local_csr(row_pointers, column_index, self.layout, self.rank)
+        self.rows = self.layout.rows[self.rank]
+        self.local_row_pointers, self.local_column_index = lrp, lcol
+        factory = ops_factory or HipShardOps
+        self.ops = factory(lrp, lcol, self.layout, self.rank, self.device)
+        self._gbuf = {}
+
+    def gather(self, x_local):
+        """[rows_p, D] -> [world * H, D]: pad to H rows, one all_gather_into_tensor (RCCL on GPUs)."""
+        D = x_local.shape[1]
+        H = self.layout.H
+        key = (D, x_local.dtype)
+        buf = self._gbuf.get(key)
+        if buf is None:
+            buf = (torch.zeros(H, D, dtype=x_local.dtype, device=x_local.device),
+                   torch.empty(self.world * H, D, dtype=x_local.dtype, device=x_local.device))
+            self._gbuf[key] = buf
+        send, recv = buf
+        send[: self.rows].copy_(x_local)
+        if self.world == 1:
+            return send
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv
+
+    def place_replicated(self, x_global):
+        """No exchange: scatter a replicated [N, D] matrix into the gathered numbering (graphs
+        that fit one GPU)."""
+        H, b = self.layout.H, self.layout.bounds
+        out = torch.zeros(self.world * H, x_global.shape[1], dtype=x_global.dtype, device=x_global.device)
+        for p in range(self.world):
+            out[p * H: p * H + b[p + 1] - b[p]] = x_global[b[p]: b[p + 1]]
+        return out
+
+    def aggregate(self, x_local):
+        """Differentiable Y_local = A_local @ all_gather(X)."""
+        return _GatherSpmm.apply(x_local, self)
+
+    def spmm(self, x_local):
+        return self.ops.spmm(self.gather(x_local))
+
+    def spmm_val(self, x_local, val_local):
+        return self.ops.spmm_val(self.gather(x_local), val_local)
+
+    def sddmm(self, x_local):
+        return self.ops.sddmm(self.gather(x_local))
+
+
+def allreduce_gradients(params, group=None):
+    """Weight gradients (KBs) are summed with one flat all-reduce; a ring is fine at this size."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off: off + g.numel()].view_as(g))
+        off += g.numel()

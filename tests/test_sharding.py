@@ -1,0 +1,120 @@
+"""Row-window sharding + the X all-gather, world_size 2 over gloo on CPU.  The three operators are
+supplied by an oracle-backed stand-in for HipShardOps (same constructor, same methods), so what is
+tested here is the partitioning, the gathered numbering, the collective and the autograd wiring."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import graphs
+from oracle import oracle as O
+
+
+class OracleShardOps:
+    """CPU stand-in: embeds the rank's rows in a square matrix over the gathered numbering."""
+
+    def __init__(self, lrp, lcol, layout, rank, device):
+        self.rows, self.num_cols, self.row_off = len(lrp) - 1, layout.num_cols, rank * layout.H
+        rp = np.zeros(self.num_cols + 1, dtype=np.int32)
+        rp[self.row_off + 1: self.row_off + self.rows + 1] = lrp[1:]
+        rp[self.row_off + self.rows + 1:] = lrp[-1]
+        self.rp, self.col = rp, np.ascontiguousarray(lcol, dtype=np.int32)
+        nw = (self.num_cols + 15) // 16
+        self.bp = np.zeros(nw, np.int32); self.e2c = np.zeros(len(lcol), np.int32); self.e2r = np.zeros(len(lcol), np.int32)
+        O.preprocess(self.col, self.rp, self.num_cols, 16, 8, self.bp, self.e2c, self.e2r)
+
+    def _sl(self, y):
+        return torch.from_numpy(np.ascontiguousarray(y[self.row_off: self.row_off + self.rows]))
+
+    def spmm(self, Xg):
+        return self._sl(O.spmm(Xg.numpy(), self.rp, self.col, self.bp, self.e2c, self.e2r, round_mode=O.ROUND_NONE))
+
+    def spmm_val(self, Xg, val):
+        return self._sl(O.spmm_val(Xg.numpy(), self.rp, self.col, val.numpy(), self.bp, self.e2c, self.e2r, round_mode=O.ROUND_NONE))
+
+    def sddmm(self, Xg):
+        return torch.from_numpy(O.sddmm(Xg.numpy(), self.rp, self.col, self.bp, self.e2c, self.e2r, round_mode=O.ROUND_NONE))
+
+
+def test_partition_rows_is_window_aligned_and_balanced():
+    import tcgnn_shard as S
+    rp, col = graphs.powerlaw_graph(5000, 30, seed=1)
+    for world in (1, 2, 3, 8):
+        b = S.partition_rows(rp, world)
+        assert b[0] == 0 and b[-1] == 5000 and len(b) == world + 1
+        assert all(x <= y for x, y in zip(b, b[1:]))
+        assert all(x % 16 == 0 for x in b[:-1])
+        nnz = [int(rp[b[p + 1]] - rp[b[p]]) for p in range(world)]
+        heaviest_window = max(int(rp[min(w + 16, 5000)] - rp[w]) for w in range(0, 5000, 16))
+        assert max(nnz) - min(nnz) <= 2 * heaviest_window + 1
+    lay = S.ShardLayout(S.partition_rows(rp, 3))
+    g = np.arange(5000)
+    m = lay.remap(g)
+    assert len(np.unique(m)) == 5000 and m.max() < lay.num_cols and lay.H % 16 == 0
+    assert np.all(np.diff(m) > 0)   # monotone: canonical rows stay canonical
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tc-gnn_atc23_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rp, col = graphs.powerlaw_graph(700, 16, seed=5)          # symmetric: A = A^T
+        n, D = 700, 24
+        rng = np.random.default_rng(0)
+        X = rng.standard_normal((n, D)).astype(np.float32)
+        att = rng.standard_normal(len(col)).astype(np.float32)
+        shard = S.RowShard(rp, col, ops_factory=OracleShardOps)
+        b0, b1 = shard.layout.bounds[rank], shard.layout.bounds[rank + 1]
+        x_local = torch.from_numpy(X[b0:b1])
+        bp = np.zeros((n + 15) // 16, np.int32); e2c = np.zeros(len(col), np.int32); e2r = np.zeros(len(col), np.int32)
+        O.preprocess(col, rp, n, 16, 8, bp, e2c, e2r)
+        Yfull = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_NONE)
+        ok = {}
+        ok["spmm"] = np.allclose(shard.spmm(x_local).numpy(), Yfull[b0:b1], atol=1e-5)
+        e0, e1 = rp[b0], rp[b1]
+        Yv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_NONE)
+        ok["spmm_val"] = np.allclose(shard.spmm_val(x_local, torch.from_numpy(att[e0:e1])).numpy(), Yv[b0:b1], atol=1e-5)
+        ef = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_NONE)
+        ok["sddmm"] = np.allclose(shard.sddmm(x_local).numpy(), ef[e0:e1], atol=1e-4)
+        # replicated placement (no exchange) gives the same gathered matrix as the collective
+        ok["replicated"] = torch.equal(shard.place_replicated(torch.from_numpy(X)), shard.gather(x_local))
+        # local-only construction (each rank materialises just its rows)
+        lrp = (rp[b0: b1 + 1] - rp[b0]).astype(np.int32)
+        shard2 = S.RowShard(bounds=shard.layout.bounds, local=(lrp, col[e0:e1]), ops_factory=OracleShardOps)
+        ok["local_ctor"] = np.allclose(shard2.spmm(x_local).numpy(), Yfull[b0:b1], atol=1e-5)
+        # autograd through the exchange: loss = sum(W-weighted aggregate); dX_local = (A dY)[rows]
+        xl = x_local.clone().requires_grad_(True)
+        w = torch.nn.Parameter(torch.ones(D, 1))
+        y = shard.aggregate(xl) @ w
+        G = rng.standard_normal((n, 1)).astype(np.float32)
+        (y * torch.from_numpy(G[b0:b1])).sum().backward()
+        dY = G @ np.ones((1, D), np.float32)
+        ok["backward"] = np.allclose(xl.grad.numpy(), O.spmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_NONE)[b0:b1], atol=1e-4)
+        S.allreduce_gradients([w])
+        ok["allreduce"] = np.allclose(w.grad.numpy()[:, 0], (Yfull * G).sum(0), rtol=1e-4, atol=1e-3)
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array([int(v) for v in ok.values()]))
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(repr(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_aggregation_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        flags = np.load(os.path.join(tmp_path, "rank%d.npy" % r))
+        assert flags.all(), open(os.path.join(tmp_path, "rank%d.txt" % r)).read()
