@@ -119,6 +119,12 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
 int tcgnn_plan_destroy(tcgnn_plan* plan);
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
 
+/* Tuning / test aid: which SpMM walk tcgnn_spmm and tcgnn_spmm_val use.  0 = automatic (default;
+ * range-blocked when the fp16 image of X exceeds the L2 and the windows are long), 1 = always the
+ * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table.  Process-wide;
+ * the environment variable TCGNN_SPMM_MODE sets the initial value. */
+int tcgnn_set_spmm_mode(int32_t mode);
+
 /* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While
  * enabled, tcgnn_spmm / tcgnn_spmm_val / tcgnn_sddmm bracket their main kernel (not the fp16
  * staging pass) with events recorded on the caller's stream, without synchronising.

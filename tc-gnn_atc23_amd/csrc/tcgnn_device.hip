@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -62,6 +63,10 @@ struct tcgnn_plan {
     int32_t* d_cols = nullptr;    // [total_wb][32] source row of each condensed column (N = none)
     uint32_t* d_mask = nullptr;   // [total_wb][16] bit c of word r: A[r][c] != 0
     int32_t* d_ebase = nullptr;   // [total_wb][16] CSR position of the first edge of row r in the tile
+    // column buckets for the range-blocked SpMM (0 = graph too sparse per window / too small)
+    int32_t nbuckets = 0, bucket_rows = 0;
+    uint32_t* d_bptr = nullptr;   // [nw_eff][nbuckets + 1] tile offset of the first tile whose first column is in bucket >= k
+    int32_t num_cus = 256;
     size_t bytes = 0;
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
     mutable std::vector<hipEvent_t> ev;
@@ -97,6 +102,11 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t
 // 11 significant bits, so the following fp32 -> fp16 conversion is exact for every element within
 // 2^-28 of the (scaled) maximum; fp16's default nearest-EVEN would differ on ties (about one
 // element in 2^13), which shows up as 2^-10-sized output differences.
+__device__ __forceinline__ float round_rna10(float x) {   // the same rounding kept in fp32 (fallback kernels)
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7f800000u) != 0x7f800000u) u = (u + 0x1000u) & 0xffffe000u;
+    return __uint_as_float(u);
+}
 __device__ __forceinline__ _Float16 to_half_rna(float x) {
     uint32_t u = __float_as_uint(x);
     if ((u & 0x7f800000u) != 0x7f800000u) u = (u + 0x1000u) & 0xffffe000u;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
 // padding columns of the tile stream point at (the reference zero-fills those, :423-424).
 template <bool VEC>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
-                                                      int32_t D, int32_t Dpad,
+                                                      int32_t D, int32_t Dpad, int32_t pitch,
                                                       _Float16* __restrict__ X16,
                                                       const uint32_t* __restrict__ hdr) {
     const int cpr = Dpad >> 3;
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
             o[j] = (row < N && d < D) ? to_half_rna(X[row * D + d] * s) : (_Float16)0.0f;
         }
     }
-    *reinterpret_cast<half8*>(X16 + row * Dpad + d0) = o;
+    *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -273,96 +283,243 @@ struct SpmmArgs {
     const uint32_t* hdr;
     float* y;
     int32_t N, D, stride, chunk0;
+    int64_t E;
+};
+
+// ---- hand-counted memory pipeline primitives ---------------------------------------------------
+// With an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of ANY ordinary load result and
+// before any LDS read it can see (cdna_hip_programming.md 5, trap (b)); that drained the next tile's
+// gather in the first version of this kernel (82 % of wave cycles in SQ_WAIT_ANY, profiles/r01).
+// So the loads inside the tile loop are hidden from the compiler and the waits are placed by hand:
+// a hidden load's register is only touched after wait_vm0() + settle(), a hidden LDS read's after
+// wait_lgkm0() + settle().  asm volatile statements keep their relative order; "memory" keeps them
+// ordered against the DMA builtin.
+__device__ __forceinline__ uint32_t hidden_load_u32(const void* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ floatx4 hidden_load_f32x4(const void* p) {   // dword-aligned is enough for global memory
+    floatx4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ half4 hidden_lds_tr16(uint32_t lds_byte_addr) {
+    half4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <class T> __device__ __forceinline__ void settle(T& v) { asm volatile("" : "+v"(v)); }
+
+// Per-lane constants and the software-pipelined walk over a run of wide blocks, shared by the
+// per-window kernel (run = every WAVES-th tile of one window) and the range-blocked kernel
+// (run = the tiles of one window inside one column range).
+template <int NT, bool VAL>
+struct TileWalker {
+    static constexpr int TILE_BYTES = NT * 1024;
+    using Img = TileImage<NT>;
+    const SpmmArgs& a;
+    const char* xbase;      // X16 + first feature column of this pass
+    int64_t stride2;        // X16 row pitch in bytes
+    uint32_t ring;          // LDS byte address of this wavefront's two tile buffers
+    int lane, g, i;
+    int drow[NT], dbyte[NT];      // DMA k fetches 16 bytes at dbyte[k] of gathered row drow[k]
+    uint32_t roff[NT][2];         // LDS byte offset this lane hands ds_read_b64_tr_b16 for slice s, K half h
+    float sa;                     // edge-value scale (VAL)
+
+    __device__ __forceinline__ TileWalker(const SpmmArgs& args, char* ring_ptr, int coloff, float sa_) : a(args), sa(sa_) {
+        lane = threadIdx.x & 63;
+        g = lane >> 4;
+        i = lane & 15;
+        xbase = reinterpret_cast<const char*>(a.x16 + coloff);
+        stride2 = (int64_t)a.stride * 2;
+        ring = (uint32_t)(uintptr_t)((LDS_AS char*)ring_ptr);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            int c;
+            Img::unslot(k * 64 + lane, drow[k], c);
+            dbyte[k] = c * 16;
+        }
+        // lane (g, i) receives K = 8g + 4h + {0..3} of column 16s + i when it points the transpose
+        // read at row 8g + 4h + (i >> 2), halves 16s + 4(i & 3) .. +3
+        const int rrow = 8 * g + (i >> 2);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int c = 2 * s + ((i >> 1) & 1);
+            roff[s][0] = (uint32_t)(Img::slot(rrow, c) * 16 + (i & 1) * 8);
+            roff[s][1] = (uint32_t)(Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
+        }
+    }
+
+    struct Ids {            // what a tile needs before its gather can be issued / its A fragment built
+        uint32_t cid[NT];
+        uint32_t m;
+        uint32_t eb;
+    };
+    __device__ __forceinline__ void request_ids(int64_t t, Ids& d) const {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) d.cid[k] = hidden_load_u32(a.cols + t * kWbCols + drow[k]);
+        d.m = hidden_load_u32(a.mask + t * kWinRows + i);
+        if constexpr (VAL) d.eb = hidden_load_u32(a.ebase + t * kWinRows + i);
+    }
+    __device__ __forceinline__ void settle_ids(Ids& d) const {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) settle(d.cid[k]);
+        settle(d.m);
+        if constexpr (VAL) settle(d.eb);
+    }
+    __device__ __forceinline__ void issue_gather(const Ids& d, int buf) const {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const char* src = xbase + (int64_t)d.cid[k] * stride2 + dbyte[k];
+            __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)(ring + buf * TILE_BYTES + k * 1024), 16, 0, 0);
+        }
+    }
+    // first CSR position of this lane's byte of row i, clamped so a 4-float read stays inside edge_val
+    __device__ __forceinline__ int64_t val_pos(uint32_t m, uint32_t eb, int& shift) const {
+        const int64_t e0 = (int64_t)eb + __popc(m & ((1u << (8 * g)) - 1u));
+        int64_t lo = e0 < a.E - 4 ? e0 : a.E - 4;
+        if (lo < 0) lo = 0;
+        shift = (int)(e0 - lo);
+        return lo;
+    }
+
+    // Ids of a tile fetched ahead of time and already settled (safe to keep in registers, copy, spill).
+    struct Carry {
+        Ids ids;
+        int64_t tile;   // -1: nothing prefetched
+    };
+
+    // acc += A(tiles t, t+step, ... < te) * X16 rows.
+    // Pipeline per iteration (tile t): issue gather(t+step) -> request vals(t+step), ids(t+2 step)
+    // -> compute tile t underneath them -> ONE wait at the bottom -> settle.  Every hidden load is
+    // requested and settled inside the same iteration, so no register with a load in flight is ever
+    // live across the loop back-edge (where the compiler may insert copies), and the hidden loads
+    // are unconditional (clamped to a valid tile) so none sits behind a branch merge either.
+    // `carry` brings in the settled ids of tile t when the previous run prefetched them and takes out
+    // those of `t_after` (first tile of the caller's next run, or -1).
+    __device__ __forceinline__ void walk(int64_t t, const int64_t te, const int64_t step, floatx4 (&acc)[NT], Carry& carry,
+                                         const int64_t t_after) const {
+        if (t >= te) return;
+        Ids cur;
+        if (carry.tile == t) {
+            cur = carry.ids;
+        } else {
+            request_ids(t, cur);
+            wait_vm0();
+            settle_ids(cur);
+        }
+        issue_gather(cur, 0);
+        uint32_t m_cur = cur.m, eb_cur = VAL ? cur.eb : 0u;
+        int shift_cur = 0;
+        floatx4 v_cur = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VAL) v_cur = hidden_load_f32x4(a.edge_val + val_pos(m_cur, eb_cur, shift_cur));
+        int64_t tn = t + step;
+        Ids nxt;
+        request_ids(tn < te ? tn : (t_after >= 0 ? t_after : t), nxt);
+        wait_vm0();
+        if constexpr (VAL) settle(v_cur);
+        settle_ids(nxt);
+        int buf = 0;
+        for (;;) {
+            const bool more = tn < te;
+            if (more) issue_gather(nxt, buf ^ 1);
+            const uint32_t m_nxt = nxt.m, eb_nxt = VAL ? nxt.eb : 0u;
+            int shift_nxt = 0;
+            floatx4 v_nxt = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (VAL) v_nxt = hidden_load_f32x4(a.edge_val + val_pos(m_nxt, eb_nxt, shift_nxt));
+            const int64_t tnn = tn + step;
+            // ids two tiles ahead; at the end of the run: the first tile of the caller's next run
+            const int64_t tfetch = !more ? tn /*unused: nxt already holds t_after's ids*/ : (tnn < te ? tnn : (t_after >= 0 ? t_after : t));
+            Ids nn;
+            request_ids(more ? tfetch : t, nn);
+            // ---- tile t
+            const uint32_t mb = (m_cur >> (8 * g)) & 0xffu;
+            half8 af;
+            if constexpr (VAL) {
+                const int nb = __popc(mb);
+                if (__builtin_expect(__any(nb + shift_cur > 4), 0)) {
+                    // rare: more than four edges of one row inside 8 columns, or the clamp at the end
+                    // of edge_val; ordinary loads (the compiler drains the queue for them)
+                    const int64_t e0 = (int64_t)eb_cur + __popc(m_cur & ((1u << (8 * g)) - 1u));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool on = (mb >> j) & 1u;
+                        const float v = on ? a.edge_val[e0 + __popc(mb & ((1u << j) - 1u))] * sa : 0.0f;
+                        af[j] = to_half_rna(v);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = __popc(mb & ((1u << j) - 1u)) + shift_cur;
+                        const float v01 = (k & 1) ? v_cur[1] : v_cur[0];
+                        const float v23 = (k & 1) ? v_cur[3] : v_cur[2];
+                        const float v = (k & 2) ? v23 : v01;
+                        af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? (_Float16)1.0f : (_Float16)0.0f;
+            }
+            const uint32_t tile = ring + buf * TILE_BYTES;
+            half4 lo[NT], hi[NT];
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                lo[s] = hidden_lds_tr16(tile + roff[s][0]);
+                hi[s] = hidden_lds_tr16(tile + roff[s][1]);
+            }
+            wait_lgkm0();
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                settle(lo[s]);
+                settle(hi[s]);
+                const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
+            }
+            // ---- everything requested above has had the whole tile to arrive
+            wait_vm0();
+            if constexpr (VAL) settle(v_nxt);
+            settle_ids(nn);
+            if (!more) {   // nxt holds the ids of t_after (requested one iteration ago, or in the prologue)
+                carry.ids = nxt;
+                carry.tile = t_after;
+                break;
+            }
+            t = tn; tn = tnn; buf ^= 1;
+            m_cur = m_nxt; eb_cur = eb_nxt; shift_cur = shift_nxt; v_cur = v_nxt;
+            nxt = nn;
+        }
+    }
 };
 
 template <int NT, int WAVES, bool VAL>
 __global__ __launch_bounds__(WAVES * 64) void spmm_kernel(const SpmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = NT * 1024;
-    constexpr int NBUF = 2;
-    using Img = TileImage<NT>;
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
     const int w = a.order[blockIdx.x];
     const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims; // first feature column of this pass
     const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
-    const int64_t stride = a.stride;
-    char* ring = smem + wave * (NBUF * TILE_BYTES);
-
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
-    const float sa = pow2f(ka);
-
-    // which (gathered row, 16-byte piece) this lane fetches in each of the NT DMA instructions
-    int drow[NT], dbyte[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        int c;
-        Img::unslot(k * 64 + lane, drow[k], c);
-        dbyte[k] = c * 16;
-    }
-    // where this lane points ds_read_b64_tr_b16 for slice s, row half h: row 8g+4h+(i>>2),
-    // halves 16s+4(i&3)..+3  -> slot 2s+((i>>1)&1), byte (i&1)*8
-    const int rrow = 8 * g + (i >> 2);
 
     floatx4 acc[NT];
 #pragma unroll
     for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    const char* xbase = reinterpret_cast<const char*>(a.x16 + coloff);
-    auto issue = [&](int64_t t, char* dst) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int cid = a.cols[t * kWbCols + drow[k]];
-            const char* src = xbase + ((int64_t)cid * stride) * 2 + dbyte[k];
-            __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(dst + k * 1024), 16, 0, 0);
-        }
-    };
-
-    int64_t t = tb + wave;
-    int buf = 0;
-    if (t < te) issue(t, ring);
-    while (t < te) {
-        const int64_t tn = t + WAVES;
-        // ---- A fragment of tile t: lane (g, r=i) holds A[r][8g .. 8g+7]
-        const uint32_t m = a.mask[t * kWinRows + i];
-        const uint32_t mb = (m >> (8 * g)) & 0xffu;
-        half8 af;
-        if constexpr (VAL) {
-            const int eb = a.ebase[t * kWinRows + i] + __popc(m & ((1u << (8 * g)) - 1u));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool on = (mb >> j) & 1u;
-                const int e = eb + __popc(mb & ((1u << j) - 1u));
-                const float v = on ? a.edge_val[e] * sa : 0.0f;
-                af[j] = to_half_rna(v);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? (_Float16)1.0f : (_Float16)0.0f;
-        }
-        if (tn < te) issue(tn, ring + (buf ^ 1) * TILE_BYTES);
-        // ---- B fragments: rows of the LDS image are K; the transpose read hands lane (g,i)
-        //      K = 8g+4h+{0..3} of column 16s+i.  (compiler inserts the vmcnt wait for the DMA)
-        const char* tile = ring + buf * TILE_BYTES;
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const int c = 2 * s + ((i >> 1) & 1);
-            const half4 lo = lds_read_tr16(tile + Img::slot(rrow, c) * 16 + (i & 1) * 8);
-            const half4 hi = lds_read_tr16(tile + Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
-            const half8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
-        }
-        t = tn;
-        buf ^= 1;
+    {
+        const TileWalker<NT, VAL> tw(a, smem + wave * (2 * TILE_BYTES), coloff, pow2f(ka));
+        typename TileWalker<NT, VAL>::Carry carry;
+        carry.tile = -1;
+        tw.walk(tb + wave, te, WAVES, acc, carry, -1);
     }
 
     // ---- combine the wavefronts' partial sums in a fixed order and store
-    const float inv = pow2f(-kx) * (VAL ? pow2f(-ka) : 1.0f); // |kx+ka| may exceed 126: two factors
-    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f;
-    (void)inv;
+    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f; // |kx + ka| may exceed 126: two factors
     const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
     if constexpr (WAVES > 1) {
         __syncthreads(); // every wave is done with its ring
@@ -398,6 +555,118 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_kernel(const SpmmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Range-blocked SpMM for graphs whose fp16 feature image does not fit the 4 MB per-XCD L2.
+//
+// PMC on the plain kernel (profiles/r01): 34 % L2 hit rate, 10 GB of fabric reads per launch for
+// 0.58 GB of algorithmic bytes - every window sweeps all of X16, and X16 (29.8 MB at Reddit D=64)
+// only fits the Infinity Cache, whose random-row gather rate (8.3 TB/s, tools/gather_bench) is
+// less than half the L2's (18 TB/s).  Here the columns are cut into R ranges of ~2 MB of X16.
+// A wavefront owns up to MAXW windows for its whole life and keeps their accumulators in
+// registers; it walks range 0 of all its windows, then range 1, ...  All resident wavefronts
+// start together and advance at the same average pace, so the rows being gathered at any moment
+// belong to one or two ranges and stay L2-resident on every XCD.  No partial sums leave the
+// registers, no atomics: the result is as deterministic as the plain kernel's.
+// ------------------------------------------------------------------------------------------
+struct SpmmBlockedArgs {
+    SpmmArgs base;
+    const uint32_t* bptr;
+    int32_t nbuckets, gsel, nranges, nw, ngroups;
+};
+
+__global__ void bucket_ptr_kernel(const int64_t* __restrict__ wb_ptr, const int32_t* __restrict__ cols, int32_t nw,
+                                  int32_t nbuckets, int32_t bucket_rows, uint32_t* bptr) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nw * (nbuckets + 1)) return;
+    const int w = (int)(idx / (nbuckets + 1)), k = (int)(idx % (nbuckets + 1));
+    const int64_t tb = wb_ptr[w];
+    const int64_t n = wb_ptr[w + 1] - tb;
+    int64_t lo = 0, hi = n;
+    if (k == nbuckets) lo = n;
+    else
+        while (lo < hi) {  // tiles are ordered by column: first tile whose first column is in bucket >= k
+            const int64_t mid = (lo + hi) >> 1;
+            if (cols[(tb + mid) * kWbCols] / bucket_rows >= k) hi = mid; else lo = mid + 1;
+        }
+    bptr[idx] = (uint32_t)lo;
+}
+
+template <int NT, int MAXW, bool VAL>
+__global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(const SpmmBlockedArgs b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_BYTES = NT * 1024;
+    const SpmmArgs& a = b.base;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims;
+    const int kx = scale_exp_from_bits(a.hdr[0]);
+    const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
+    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f;
+    const TileWalker<NT, VAL> tw(a, smem + wave * (2 * TILE_BYTES), coloff, pow2f(ka));
+
+    const int gw = blockIdx.x * 4 + wave, gwn = gridDim.x * 4;
+    for (int grp = gw; grp < b.ngroups; grp += gwn) {
+        int wj[MAXW];
+        int64_t tbj[MAXW];
+        uint32_t done[MAXW];
+        floatx4 acc[MAXW][NT];
+#pragma unroll
+        for (int j = 0; j < MAXW; ++j) {
+            const int idx = grp + j * b.ngroups;   // strided picks from the heaviest-first order: balanced groups
+            wj[j] = idx < b.nw ? __builtin_amdgcn_readfirstlane(a.order[idx]) : -1;
+            tbj[j] = wj[j] >= 0 ? a.wb_ptr[wj[j]] : 0;
+            done[j] = 0;
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[j][s] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+        typename TileWalker<NT, VAL>::Carry carry;
+        carry.tile = -1;
+        // run q = (range r, window j); its bounds are looked up one run ahead so the walk can prefetch
+        // the ids of the next run's first tile while it finishes the current one
+        uint32_t nend[MAXW];
+#pragma unroll
+        for (int j = 0; j < MAXW; ++j) nend[j] = wj[j] >= 0 ? b.bptr[(int64_t)wj[j] * (b.nbuckets + 1) + b.gsel] : 0u;
+        for (int r = 0; r < b.nranges; ++r) {
+            uint32_t end[MAXW], after[MAXW];
+#pragma unroll
+            for (int j = 0; j < MAXW; ++j) {
+                end[j] = nend[j];
+                after[j] = (wj[j] >= 0 && r + 1 < b.nranges) ? b.bptr[(int64_t)wj[j] * (b.nbuckets + 1) + (int64_t)(r + 2) * b.gsel] : end[j];
+                nend[j] = after[j];
+            }
+#pragma unroll
+            for (int j = 0; j < MAXW; ++j) {
+                if (wj[j] < 0) continue;
+                // first tile of the next non-empty run: window j+1.. of this range, else window 0.. of the next
+                int64_t t_after = -1;
+#pragma unroll
+                for (int jj = MAXW - 1; jj >= 0; --jj)
+                    if (wj[jj] >= 0 && after[jj] > end[jj]) t_after = tbj[jj] + end[jj];
+#pragma unroll
+                for (int jj = MAXW - 1; jj > j; --jj)
+                    if (wj[jj] >= 0 && end[jj] > done[jj]) t_after = tbj[jj] + done[jj];
+                tw.walk(tbj[j] + done[j], tbj[j] + end[j], 1, acc[j], carry, t_after);
+                done[j] = end[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXW; ++j) {
+            if (wj[j] < 0) continue;
+            const int64_t row0 = (int64_t)wj[j] * kWinRows + 4 * g;
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const int colg = coloff + 16 * s + i;
+                if (colg < a.D) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[j][s][ii] * inv1 * inv2;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // SDDMM:  ef[e] = <X16[row e], X16[col e]>
 // ------------------------------------------------------------------------------------------
 struct SddmmArgs {
@@ -412,8 +681,23 @@ struct SddmmArgs {
     int32_t N, Nc, row_off, Dpad, stride;
 };
 
-// KS = number of 32-wide k steps held in registers for the window rows (0: loop at run time and
-// re-read them per tile; used for D > 128).
+__device__ __forceinline__ half8 hidden_load_h8(const void* p) {
+    floatx4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return __builtin_bit_cast(half8, v);
+}
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));   // a register tuple the asm constraints accept (HIP's uint4 is a struct)
+__device__ __forceinline__ uintx4 hidden_load_u32x4(const void* p) {
+    uintx4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// KS = number of 32-wide k steps (D <= 32*KS <= 128).  The window rows (A operand) stay in
+// registers; the neighbour rows of the NEXT tile (both 16-column halves, 2*KS 16-byte loads per
+// lane) are requested before the current tile is multiplied, so a wavefront pays one memory
+// latency per 32 condensed columns instead of one per 16 (first version) - same hidden-load
+// discipline as TileWalker: requested and settled inside one iteration.
 template <int KS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
     const int lane = threadIdx.x & 63;
@@ -424,20 +708,112 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
     const int64_t stride = a.stride;
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const float inv = pow2f(-kx);
-    const int ksteps = (a.Dpad + 31) >> 5;
     const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
     int64_t arow = (int64_t)w * kWinRows + i;
     arow = arow < a.N ? arow + a.row_off : a.Nc;
     const _Float16* ap = a.x16 + arow * stride + 8 * g;
-    half8 af[KS > 0 ? KS : 1];
-    if constexpr (KS > 0) {
+    half8 af[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-    }
+    for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
 
+    struct Ids { uint32_t cid[2]; uintx4 m4, eb4; };
+    auto request_ids = [&](int64_t t, Ids& d) {
+        d.cid[0] = hidden_load_u32(a.cols + t * kWbCols + i);
+        d.cid[1] = hidden_load_u32(a.cols + t * kWbCols + 16 + i);
+        d.m4 = hidden_load_u32x4(a.mask + t * kWinRows + 4 * g);
+        d.eb4 = hidden_load_u32x4(a.ebase + t * kWinRows + 4 * g);
+    };
+    auto settle_ids = [&](Ids& d) { settle(d.cid[0]); settle(d.cid[1]); settle(d.m4); settle(d.eb4); };
+    auto request_b = [&](const Ids& d, half8 (&b)[2][KS]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // a lane whose k slice lies past Dpad re-reads slice 0 (valid memory) and is zeroed at use
+            const _Float16* bp = a.x16 + (int64_t)d.cid[sub] * stride;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[sub][ks] = hidden_load_h8(bp + ((ks * 32 + 8 * g < a.Dpad) ? ks * 32 + 8 * g : 0));
+        }
+    };
+    auto settle_b = [&](half8 (&b)[2][KS]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) settle(b[sub][ks]);
+    };
+
+    int64_t t = tb + wave;
+    if (t >= te) return;
+    Ids cur, nxt;
+    half8 bcur[2][KS], bnxt[2][KS];
+    request_ids(t, cur);
+    wait_vm0();
+    settle_ids(cur);
+    request_b(cur, bcur);
+    int64_t tn = t + WAVES;
+    request_ids(tn < te ? tn : t, nxt);
+    wait_vm0();
+    settle_b(bcur);
+    settle_ids(nxt);
+    for (;;) {
+        const bool more = tn < te;
+        request_b(nxt, bnxt);                       // valid tile even when !more (clamped), result unused then
+        const int64_t tnn = tn + WAVES;
+        Ids nn;
+        request_ids(tnn < te ? tnn : t, nn);
+        // ---- tile t
+        const uint32_t mm[4] = {cur.m4[0], cur.m4[1], cur.m4[2], cur.m4[3]};
+        const uint32_t ee[4] = {cur.eb4[0], cur.eb4[1], cur.eb4[2], cur.eb4[3]};
+        auto half_tile = [&](const int sub, const half8 (&bsub)[KS]) {
+            const uint32_t anyrow = ((mm[0] | mm[1] | mm[2] | mm[3]) >> (16 * sub)) & 0xffffu;
+            if (__any(anyrow != 0u)) {              // skip a 16-column half no edge lands in
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const half8 bf = (ks * 32 + 8 * g < a.Dpad) ? bsub[ks] : hz;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf, acc, 0, 0, 0);
+                }
+                // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
+                const int bit = 16 * sub + i;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if ((mm[ii] >> bit) & 1u) {
+                        const int64_t e = (int64_t)ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
+                        a.ef[e] = acc[ii] * inv * inv;
+                    }
+                }
+            }
+        };
+        half_tile(0, bcur[0]);
+        half_tile(1, bcur[1]);
+        wait_vm0();
+        settle_b(bnxt);
+        settle_ids(nn);
+        if (!more) break;
+        t = tn; tn = tnn;
+        cur = nxt; nxt = nn;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bcur[sub][ks] = bnxt[sub][ks];
+    }
+}
+
+// Run-time-K variant for D > 128: window rows are re-read per tile (L1-resident), ordinary loads.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int w = a.order[blockIdx.x];
+    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+    const int64_t stride = a.stride;
+    const float inv = pow2f(-scale_exp_from_bits(a.hdr[0]));
+    const int ksteps = (a.Dpad + 31) >> 5;
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t arow = (int64_t)w * kWinRows + i;
+    arow = arow < a.N ? arow + a.row_off : a.Nc;
+    const _Float16* ap = a.x16 + arow * stride + 8 * g;
     for (int64_t t = tb + wave; t < te; t += WAVES) {
         const uint4 m4 = *reinterpret_cast<const uint4*>(a.mask + t * kWinRows + 4 * g);
         const int4 eb4 = *reinterpret_cast<const int4*>(a.ebase + t * kWinRows + 4 * g);
@@ -446,30 +822,21 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t anyrow = ((m4.x | m4.y | m4.z | m4.w) >> (16 * sub)) & 0xffffu;
-            if (!__any(anyrow != 0u)) continue; // no edge lands in this 16-column half
+            if (!__any(anyrow != 0u)) continue;
             const int cid = a.cols[t * kWbCols + 16 * sub + i];
             const _Float16* bp = a.x16 + (int64_t)cid * stride + 8 * g;
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (KS > 0) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const half8 bf = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf, acc, 0, 0, 0);
-                }
-            } else {
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    const bool ok = ks * 32 + 8 * g < a.Dpad;
-                    const half8 av = ok ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-                    const half8 bf = ok ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
-                }
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const bool ok = ks * 32 + 8 * g < a.Dpad;
+                const half8 av = ok ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
+                const half8 bf = ok ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
             }
-            // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
             const int bit = 16 * sub + i;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 if ((mm[ii] >> bit) & 1u) {
-                    const int e = ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
+                    const int64_t e = (int64_t)ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
                     a.ef[e] = acc[ii] * inv * inv;
                 }
             }
@@ -491,7 +858,7 @@ __global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __rest
     const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
     for (int d = lane; d < D; d += 64) {
         float s = 0.f;
-        for (int64_t e = e0; e < e1; ++e) s += val[e] * X[(int64_t)col[e] * D + d];
+        for (int64_t e = e0; e < e1; ++e) s += round_rna10(val[e]) * round_rna10(X[(int64_t)col[e] * D + d]);
         Y[row * D + d] = s;
     }
 }
@@ -507,7 +874,7 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restric
     for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
         const float* xc = X + (int64_t)col[e] * D;
         float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += xr[d] * xc[d];
+        for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0) ef[e] = s;
@@ -544,6 +911,27 @@ static hipError_t launch_spmm_any(bool val, int waves, int nt, const SpmmArgs& a
     return val ? launch_spmm_nt<1, true>(nt, args, nwin, nchunks, stream) : launch_spmm_nt<1, false>(nt, args, nwin, nchunks, stream);
 }
 
+// windows owned by one wavefront of the range-blocked kernel (accumulators: MAXW * NT * 4 registers)
+static constexpr int blocked_maxw(int nt, bool val) { return (nt <= 4 && !val) ? 4 : 2; }
+
+template <int NT, bool VAL>
+static hipError_t launch_blocked_one(const SpmmBlockedArgs& args, int nwg, int nchunks, hipStream_t stream) {
+    constexpr int MAXW = blocked_maxw(NT, VAL);
+    const size_t lds = (size_t)4 * 2 * NT * 1024;
+    hipLaunchKernelGGL((spmm_blocked_kernel<NT, MAXW, VAL>), dim3((unsigned)nwg, (unsigned)nchunks), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
+static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& args, int nwg, int nchunks, hipStream_t stream) {
+#define TCGNN_BLK_CASE(n) case n: return val ? launch_blocked_one<n, true>(args, nwg, nchunks, stream) : launch_blocked_one<n, false>(args, nwg, nchunks, stream);
+    switch (nt) {
+        TCGNN_BLK_CASE(1) TCGNN_BLK_CASE(2) TCGNN_BLK_CASE(3) TCGNN_BLK_CASE(4)
+        TCGNN_BLK_CASE(5) TCGNN_BLK_CASE(6) TCGNN_BLK_CASE(7) TCGNN_BLK_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TCGNN_BLK_CASE
+}
+
 template <int WAVES>
 static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipStream_t stream) {
     const dim3 grid((unsigned)nwin), block(WAVES * 64);
@@ -552,16 +940,28 @@ static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipSt
         case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES>), grid, block, 0, stream, args); break;
         case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES>), grid, block, 0, stream, args); break;
         case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES>), grid, block, 0, stream, args); break;
-        default: hipLaunchKernelGGL((sddmm_kernel<0, WAVES>), grid, block, 0, stream, args); break;
+        default: hipLaunchKernelGGL((sddmm_wide_kernel<WAVES>), grid, block, 0, stream, args); break;
     }
     return hipGetLastError();
 }
 
+static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
+static constexpr size_t kRangeTargetBytes = 2u << 20;  // X16 bytes per column range (4 MB L2 per XCD)
 static constexpr size_t kHdrBytes = 256;
 
+// Row pitch of the fp16 image in halves: a gathered row should touch as few 128-byte lines as
+// possible (a 96-byte row at pitch 96 straddles two lines three times out of four: D = 41..48 ran
+// slower than D = 64), so rows up to 128 B are padded to a power of two and longer ones to whole lines.
+static int x16_pitch(int dpad) {
+    const int bytes = dpad * 2;
+    if (bytes <= 128) { int p = 32; while (p < bytes) p <<= 1; return p / 2; }
+    return round_up(bytes, 128) / 2;
+}
+
 static size_t workspace_bytes_for(int32_t N, int32_t D) {
-    const size_t dpad = (size_t)round_up(D, 16);
+    const size_t dpad = (size_t)x16_pitch(round_up(D, 16));
     const size_t body = ((size_t)N + 1) * dpad * sizeof(_Float16);
     return kHdrBytes + ((body + 255) / 256) * 256;
 }
@@ -569,13 +969,14 @@ static size_t workspace_bytes_for(int32_t N, int32_t D) {
 // enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
-                          const _Float16** x16_out, int* dpad_out) {
+                          const _Float16** x16_out, int* dpad_out, int* pitch_out) {
     const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
     uint32_t* hdr = static_cast<uint32_t*>(ws);
     _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
     const int dpad = round_up(D, 16);
+    const int pitch = x16_pitch(dpad);
     HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
     const int64_t nx = (int64_t)plan->Nc * D;
     if (nx > 0) {
@@ -589,10 +990,10 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
-    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, x16, hdr);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, x16, hdr);
+    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
     HIP_TRY(hipGetLastError());
-    *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad;
+    *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
     return TCGNN_OK;
 }
 
@@ -603,19 +1004,39 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     if (plan->N == 0) return TCGNN_OK;
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
         HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
-    if (d_val && !plan->canonical) {
+    if (d_val && (!plan->canonical || plan->E < 4)) {
         hipLaunchKernelGGL(spmm_val_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream,
                            plan->rowptr, plan->col, d_val, d_X, d_Y, plan->N, D);
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     }
-    const uint32_t* hdr; const _Float16* x16; int dpad;
-    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad);
+    const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
+    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
-    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, dpad, 0};
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
+    // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
+    const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
+    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked
+    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || x16_bytes > kBlockedMinBytes);
+    if (blocked) {
+        size_t range_bytes = kRangeTargetBytes;
+        if (const char* e = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // tuning experiments only
+        int nranges = 1;
+        while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
+        SpmmBlockedArgs b{a, plan->d_bptr, plan->nbuckets, plan->nbuckets / nranges, nranges, plan->nw_eff, 0};
+        auto wgs = [&](int nt) {   // persistent grid: what is resident at once (LDS: 8*nt KB per workgroup; registers: 4 or 2 per CU)
+            const int maxw = blocked_maxw(nt, d_val != nullptr);
+            b.ngroups = (plan->nw_eff + maxw - 1) / maxw;
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, 160 / (8 * nt)));
+            return std::min((b.ngroups + 3) / 4, plan->num_cus * per_cu);
+        };
+        if (nfull) { b.base.chunk0 = 0; const int n = wgs(8); HIP_TRY(launch_blocked_any(d_val != nullptr, 8, b, n, nfull, stream)); }
+        if (rem) { b.base.chunk0 = nfull; const int n = wgs(rem); HIP_TRY(launch_blocked_any(d_val != nullptr, rem, b, n, 1, stream)); }
+        return TCGNN_OK;
+    }
     if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, 8, a, plan->nw_eff, nfull, stream)); }
     if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, rem, a, plan->nw_eff, 1, stream)); }
     return TCGNN_OK;
@@ -629,7 +1050,7 @@ extern "C" {
 int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
-    (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase);
+    (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -701,6 +1122,30 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build: %s", hipGetErrorString(e)));
     if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
     p->canonical = flags[1] ? 0 : 1;
+    {   // column buckets for the range-blocked SpMM: only when windows are long (>= 2 tiles per bucket on
+        // average) and numerous enough to fill the chip with one wavefront per 4 windows
+        hipDeviceProp_t prop;
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess) p->num_cus = prop.multiProcessorCount;
+        int nb = 8;
+        while (nb < 128 && (int64_t)num_cols / nb > 4096) nb <<= 1;
+        if (nw >= 4 * p->num_cus && p->total_wb >= (int64_t)2 * nb * nw) {
+            p->nbuckets = nb;
+            p->bucket_rows = (int32_t)(((int64_t)num_cols + nb - 1) / nb);
+            if (p->bucket_rows < 1) p->bucket_rows = 1;
+            const size_t b_bp = (size_t)nw * (nb + 1) * sizeof(uint32_t);
+            e = hipMalloc(&p->d_bptr, b_bp);
+            if (e == hipSuccess) {
+                const int64_t total = (int64_t)nw * (nb + 1);
+                hipLaunchKernelGGL(bucket_ptr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, nw, nb,
+                                   p->bucket_rows, p->d_bptr);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            }
+            if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "bucket table: %s", hipGetErrorString(e)));
+            p->bytes += b_bp;
+        }
+    }
     *plan_out = p;
     return TCGNN_OK;
 }
@@ -718,6 +1163,12 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
     info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
     info->canonical = plan->canonical; info->waves_per_window = plan->waves;
+    return TCGNN_OK;
+}
+
+int tcgnn_set_spmm_mode(int32_t mode) {
+    if (mode < 0 || mode > 2) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain) or 2 (range-blocked)");
+    g_spmm_mode = mode;
     return TCGNN_OK;
 }
 
@@ -772,10 +1223,10 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         return TCGNN_OK;
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
-    const uint32_t* hdr; const _Float16* x16; int dpad;
-    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad);
+    const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, dpad};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream);
     hipError_t e = plan->waves == 4 ? launch_sddmm_ks<4>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1>(ks, a, plan->nw_eff, stream);

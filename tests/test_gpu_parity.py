@@ -104,6 +104,36 @@ def test_three_kernels_match_oracle(dev, T, case, D):
     assert_parity(ef[0].cpu().numpy(), O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32), ef64, absef, "sddmm", unit)
 
 
+@pytest.mark.parametrize("D", [16, 64, 41, 128, 160])
+def test_range_blocked_walk_matches_oracle_and_plain_walk(dev, T, D):
+    """The persistent, column-range-blocked SpMM (chosen automatically for big feature matrices) is
+    forced here on a graph small enough for the oracle; it must agree with the oracle and with the
+    per-window kernel."""
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(16448, 180, seed=12)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    att = rng.standard_normal(nnz).astype(np.float32)
+    tX, tatt = to_dev(dev, X, att)
+    out = {}
+    try:
+        for mode in (1, 2):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            out[mode] = (T.forward(tX, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy(),
+                         T.forward_AGNN(tX, trp, tcol, tatt.view(1, -1), tbp, te2c, te2r)[0].cpu().numpy())
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    Y64, absY = O.spmm_f64(X, rp, col)
+    Yv64, absYv = O.spmm_f64(X, rp, col, att)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    refv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    for mode in (1, 2):
+        assert_parity(out[mode][0], ref, Y64, absY, "spmm mode %d" % mode)
+        assert_parity(out[mode][1], refv, Yv64, absYv, "spmm_val mode %d" % mode)
+
+
 def test_metadata_from_reference_fixture_feeds_the_kernels(dev, T):
     """The five legacy arrays exactly as the reference's preprocess wrote them (golden fixture)."""
     f = np.load(os.path.join(GOLD, "sgt_powerlaw_n1000.npz"))
@@ -149,10 +179,11 @@ def test_non_canonical_rows_take_the_fallback_kernels(dev, T):
     X = rng.standard_normal((500, 48)).astype(np.float32); att = rng.standard_normal(len(col)).astype(np.float32)
     tX, tatt = to_dev(dev, X, att)
     assert np.abs(T.forward(tX, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy() - O.spmm(X, rp, col, bp, e2c, e2r)).max() < 1e-3
+    # the fallback kernels round operands like the reference too (TF32), so compare in that mode
     Yv = T.forward_AGNN(tX, trp, tcol, tatt.view(1, -1), tbp, te2c, te2r)[0].cpu().numpy()
-    assert np.abs(Yv - O.spmm_f64(X, rp, col, att)[0]).max() < 1e-3
+    assert np.abs(Yv - O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)).max() < 1e-4
     ef = T.forward_ef(tX, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy()
-    assert np.abs(ef - O.sddmm_f64(X, rp, col)[0]).max() < 1e-3
+    assert np.abs(ef - O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)).max() < 1e-4
 
 
 def test_layers_with_hip_kernels_reproduce_reference_fixture(dev, T):
