@@ -30,6 +30,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "tcgnn.h"
@@ -284,34 +285,85 @@ struct SpmmArgs {
     float* y;
     int32_t N, D, stride, chunk0;
     int64_t E;
+    int32_t xrows;   // rows of X16 including the zero sentinel row
 };
 
-// ---- hand-counted memory pipeline primitives ---------------------------------------------------
+// ---- memory pipeline discipline -----------------------------------------------------------------
 // With an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of ANY ordinary load result and
-// before any LDS read it can see (cdna_hip_programming.md 5, trap (b)); that drained the next tile's
-// gather in the first version of this kernel (82 % of wave cycles in SQ_WAIT_ANY, profiles/r01).
-// So the loads inside the tile loop are hidden from the compiler and the waits are placed by hand:
-// a hidden load's register is only touched after wait_vm0() + settle(), a hidden LDS read's after
-// wait_lgkm0() + settle().  asm volatile statements keep their relative order; "memory" keeps them
-// ordered against the DMA builtin.
-__device__ __forceinline__ uint32_t hidden_load_u32(const void* p) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ floatx4 hidden_load_f32x4(const void* p) {   // dword-aligned is enough for global memory
-    floatx4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ half4 hidden_lds_tr16(uint32_t lds_byte_addr) {
-    half4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
-    return v;
-}
+// before any LDS read it can see (cdna_hip_programming.md 5, trap (b)) - that drained the next
+// tile's gather in the first version of these kernels.  Hiding loads in inline asm avoids the
+// drain, but a VGPR with an asm load in flight is a trap of its own: the register allocator may
+// copy it before our wait (found by tools/audit_hidden_loads.py: `v_mov_b32 v2, v3` scheduled
+// above the s_waitcnt).  So the rule here is: NO VGPR EVER HAS A LOAD IN FLIGHT OUTSIDE ONE ASM
+// STATEMENT.
+//   * global -> LDS: LDS-DMA builtins only (per-tile metadata, gathered rows, edge values, SDDMM
+//     operands).  No VGPR destination; in flight across loop iterations; retired by wait_vm0().
+//   * LDS -> VGPR: the generated blocks of tcgnn_lds_blocks.inc, whose s_waitcnt lgkmcnt(0) is in
+//     the same asm statement as the reads (early-clobber outputs).
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+#include "tcgnn_lds_blocks.inc"
+
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-template <class T> __device__ __forceinline__ void settle(T& v) { asm volatile("" : "+v"(v)); }
+
+template <int N> __device__ __forceinline__ void lds_ids_block(const uint32_t* ad, uint32_t* v, uint32_t qaddr, uintx4& q) {
+    if constexpr (N == 1) lds_ids_block1(ad, v, qaddr, q);
+    else if constexpr (N == 2) lds_ids_block2(ad, v, qaddr, q);
+    else if constexpr (N == 3) lds_ids_block3(ad, v, qaddr, q);
+    else if constexpr (N == 4) lds_ids_block4(ad, v, qaddr, q);
+    else if constexpr (N == 5) lds_ids_block5(ad, v, qaddr, q);
+    else if constexpr (N == 6) lds_ids_block6(ad, v, qaddr, q);
+    else if constexpr (N == 7) lds_ids_block7(ad, v, qaddr, q);
+    else if constexpr (N == 8) lds_ids_block8(ad, v, qaddr, q);
+    else if constexpr (N == 9) lds_ids_block9(ad, v, qaddr, q);
+    else lds_ids_block10(ad, v, qaddr, q);
+}
+template <int N, int OFF> __device__ __forceinline__ void lds_q_block(const uint32_t* ad, uintx4* q) {
+    if constexpr (N == 1) lds_q_block1<OFF>(ad, q);
+    else if constexpr (N == 2) lds_q_block2<OFF>(ad, q);
+    else if constexpr (N == 3) lds_q_block3<OFF>(ad, q);
+    else if constexpr (N == 4) lds_q_block4<OFF>(ad, q);
+    else if constexpr (N == 5) lds_q_block5<OFF>(ad, q);
+    else if constexpr (N == 6) lds_q_block6<OFF>(ad, q);
+    else if constexpr (N == 7) lds_q_block7<OFF>(ad, q);
+    else if constexpr (N == 8) lds_q_block8<OFF>(ad, q);
+    else if constexpr (N == 9) lds_q_block9<OFF>(ad, q);
+    else lds_q_block10<OFF>(ad, q);
+}
+template <int K, int OFF> __device__ __forceinline__ void lds_tr_block(const uint32_t (*ad)[2], half4* lo, half4* hi) {
+    if constexpr (K == 1) lds_tr_block1<OFF>(ad, lo, hi);
+    else if constexpr (K == 2) lds_tr_block2<OFF>(ad, lo, hi);
+    else if constexpr (K == 3) lds_tr_block3<OFF>(ad, lo, hi);
+    else if constexpr (K == 4) lds_tr_block4<OFF>(ad, lo, hi);
+    else { lds_tr_block4<OFF>(ad, lo, hi); lds_tr_block<K - 4, OFF>(ad + 4, lo + 4, hi + 4); }
+}
+
+// 256-entry table: byte of adjacency bits -> the eight fp16 {0,1} values of a binary A fragment.
+// One LDS read replaces ~28 VALU instructions per tile.
+__device__ __forceinline__ void fill_afrag_table(char* tab) {
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((e >> j) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
+        *reinterpret_cast<half8*>(tab + e * 16) = v;
+    }
+}
+
+// Per-tile metadata travels as ONE 256-byte DMA: lane l < 32 fetches cols[t][l], lanes 32..47
+// mask[t][l-32], lanes 48..63 ebase[t][l-48]; it lands lane-linear in a per-wavefront pad.
+struct MetaSource {
+    const char* base;   // this lane's element of tile 0
+    int shift;          // log2(bytes per tile) of the array this lane reads
+    __device__ __forceinline__ MetaSource(const int32_t* cols, const uint32_t* mask, const int32_t* ebase, int lane) {
+        if (lane < 32) { base = reinterpret_cast<const char*>(cols + lane); shift = 7; }
+        else if (lane < 48) { base = reinterpret_cast<const char*>(mask + (lane - 32)); shift = 6; }
+        else { base = reinterpret_cast<const char*>(ebase + (lane - 48)); shift = 6; }
+    }
+    __device__ __forceinline__ void dma(int64_t t, uint32_t pad_lds) const {
+        const char* src = base + (t << shift);
+        __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)pad_lds, 4, 0, 0);
+    }
+};
+static constexpr int kPadBytes = 256;
 
 // Per-lane constants and the software-pipelined walk over a run of wide blocks, shared by the
 // per-window kernel (run = every WAVES-th tile of one window) and the range-blocked kernel
@@ -319,184 +371,173 @@ template <class T> __device__ __forceinline__ void settle(T& v) { asm volatile("
 template <int NT, bool VAL>
 struct TileWalker {
     static constexpr int TILE_BYTES = NT * 1024;
+    static constexpr int WAVE_LDS = 2 * TILE_BYTES + kPadBytes + (VAL ? 1024 : 0);  // two tile buffers, metadata pad, edge values
+    static constexpr int NIDS = NT + 1 + (VAL ? 1 : 0);
     using Img = TileImage<NT>;
     const SpmmArgs& a;
-    const char* xbase;      // X16 + first feature column of this pass
-    int64_t stride2;        // X16 row pitch in bytes
-    uint32_t ring;          // LDS byte address of this wavefront's two tile buffers
+    __amdgpu_buffer_rsrc_t xrsrc; // X16 as a structured buffer: record = one fp16 row (pitch bytes);
+                                  // the gather address row*pitch + offset is formed by the hardware
+    MetaSource meta;
+    uint32_t ring, pad, vpad, atab; // LDS byte addresses: tile buffers, metadata pad, edge-value pad, A table
     int lane, g, i;
-    int drow[NT], dbyte[NT];      // DMA k fetches 16 bytes at dbyte[k] of gathered row drow[k]
-    uint32_t roff[NT][2];         // LDS byte offset this lane hands ds_read_b64_tr_b16 for slice s, K half h
+    uint32_t doff[NT];            // byte offset inside a gathered row: first feature column of the pass + 16-byte piece
+    uint32_t idaddr[NIDS];        // LDS addresses in the pad: row id of DMA k for this lane, mask word, edge offset
+    uint32_t raddr[NT][2];        // LDS address (buffer 0) this lane hands ds_read_b64_tr_b16 for slice s, K half h
     float sa;                     // edge-value scale (VAL)
 
-    __device__ __forceinline__ TileWalker(const SpmmArgs& args, char* ring_ptr, int coloff, float sa_) : a(args), sa(sa_) {
+    __device__ __forceinline__ TileWalker(const SpmmArgs& args, char* wave_lds, char* atab_ptr, int coloff, float sa_)
+        : a(args), meta(args.cols, args.mask, args.ebase, threadIdx.x & 63), sa(sa_) {
         lane = threadIdx.x & 63;
         g = lane >> 4;
         i = lane & 15;
-        xbase = reinterpret_cast<const char*>(a.x16 + coloff);
-        stride2 = (int64_t)a.stride * 2;
-        ring = (uint32_t)(uintptr_t)((LDS_AS char*)ring_ptr);
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.xrows, 0x00020000);
+        ring = (uint32_t)(uintptr_t)((LDS_AS char*)wave_lds);
+        pad = ring + 2 * TILE_BYTES;
+        vpad = pad + kPadBytes;
+        atab = (uint32_t)(uintptr_t)((LDS_AS char*)atab_ptr);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
-            int c;
-            Img::unslot(k * 64 + lane, drow[k], c);
-            dbyte[k] = c * 16;
+            int row, c;
+            Img::unslot(k * 64 + lane, row, c);
+            idaddr[k] = pad + (uint32_t)row * 4u;
+            doff[k] = (uint32_t)(coloff * 2 + c * 16);
         }
+        idaddr[NT] = pad + 128u + (uint32_t)i * 4u;
+        if constexpr (VAL) idaddr[NT + 1] = pad + 192u + (uint32_t)i * 4u;
         // lane (g, i) receives K = 8g + 4h + {0..3} of column 16s + i when it points the transpose
         // read at row 8g + 4h + (i >> 2), halves 16s + 4(i & 3) .. +3
         const int rrow = 8 * g + (i >> 2);
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             const int c = 2 * s + ((i >> 1) & 1);
-            roff[s][0] = (uint32_t)(Img::slot(rrow, c) * 16 + (i & 1) * 8);
-            roff[s][1] = (uint32_t)(Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
+            raddr[s][0] = ring + (uint32_t)(Img::slot(rrow, c) * 16 + (i & 1) * 8);
+            raddr[s][1] = ring + (uint32_t)(Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
         }
     }
 
-    struct Ids {            // what a tile needs before its gather can be issued / its A fragment built
-        uint32_t cid[NT];
-        uint32_t m;
-        uint32_t eb;
+    struct Cur {            // the tile being multiplied: its mask word, edge offset, value-window shift
+        uint32_t m, eb;
+        int shift;
     };
-    __device__ __forceinline__ void request_ids(int64_t t, Ids& d) const {
+    template <int BUF> __device__ __forceinline__ void dma_gather(const uint32_t* cid) const {
 #pragma unroll
-        for (int k = 0; k < NT; ++k) d.cid[k] = hidden_load_u32(a.cols + t * kWbCols + drow[k]);
-        d.m = hidden_load_u32(a.mask + t * kWinRows + i);
-        if constexpr (VAL) d.eb = hidden_load_u32(a.ebase + t * kWinRows + i);
+        for (int k = 0; k < NT; ++k)
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16,
+                                                        (int)cid[k], (int)doff[k], 0, 0, 0);
     }
-    __device__ __forceinline__ void settle_ids(Ids& d) const {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) settle(d.cid[k]);
-        settle(d.m);
-        if constexpr (VAL) settle(d.eb);
-    }
-    __device__ __forceinline__ void issue_gather(const Ids& d, int buf) const {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const char* src = xbase + (int64_t)d.cid[k] * stride2 + dbyte[k];
-            __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)(ring + buf * TILE_BYTES + k * 1024), 16, 0, 0);
-        }
-    }
-    // first CSR position of this lane's byte of row i, clamped so a 4-float read stays inside edge_val
-    __device__ __forceinline__ int64_t val_pos(uint32_t m, uint32_t eb, int& shift) const {
-        const int64_t e0 = (int64_t)eb + __popc(m & ((1u << (8 * g)) - 1u));
+    // edge values of this lane's byte of row i: 4 consecutive floats starting at the first edge of
+    // the byte, clamped so the read stays inside edge_val; lands in this lane's slot of the value pad
+    __device__ __forceinline__ void dma_vals(Cur& c) const {
+        const int64_t e0 = (int64_t)c.eb + __popc(c.m & ((1u << (8 * g)) - 1u));
         int64_t lo = e0 < a.E - 4 ? e0 : a.E - 4;
         if (lo < 0) lo = 0;
-        shift = (int)(e0 - lo);
-        return lo;
+        c.shift = (int)(e0 - lo);
+        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo), (LDS_AS void*)(uintptr_t)vpad, 16, 0, 0);
     }
 
-    // Ids of a tile fetched ahead of time and already settled (safe to keep in registers, copy, spill).
-    struct Carry {
-        Ids ids;
-        int64_t tile;   // -1: nothing prefetched
-    };
-
-    // acc += A(tiles t, t+step, ... < te) * X16 rows.
-    // Pipeline per iteration (tile t): issue gather(t+step) -> request vals(t+step), ids(t+2 step)
-    // -> compute tile t underneath them -> ONE wait at the bottom -> settle.  Every hidden load is
-    // requested and settled inside the same iteration, so no register with a load in flight is ever
-    // live across the loop back-edge (where the compiler may insert copies), and the hidden loads
-    // are unconditional (clamped to a valid tile) so none sits behind a branch merge either.
-    // `carry` brings in the settled ids of tile t when the previous run prefetched them and takes out
-    // those of `t_after` (first tile of the caller's next run, or -1).
-    __device__ __forceinline__ void walk(int64_t t, const int64_t te, const int64_t step, floatx4 (&acc)[NT], Carry& carry,
-                                         const int64_t t_after) const {
-        if (t >= te) return;
-        Ids cur;
-        if (carry.tile == t) {
-            cur = carry.ids;
-        } else {
-            request_ids(t, cur);
-            wait_vm0();
-            settle_ids(cur);
-        }
-        issue_gather(cur, 0);
-        uint32_t m_cur = cur.m, eb_cur = VAL ? cur.eb : 0u;
-        int shift_cur = 0;
-        floatx4 v_cur = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (VAL) v_cur = hidden_load_f32x4(a.edge_val + val_pos(m_cur, eb_cur, shift_cur));
-        int64_t tn = t + step;
-        Ids nxt;
-        request_ids(tn < te ? tn : (t_after >= 0 ? t_after : t), nxt);
-        wait_vm0();
-        if constexpr (VAL) settle(v_cur);
-        settle_ids(nxt);
-        int buf = 0;
-        for (;;) {
-            const bool more = tn < te;
-            if (more) issue_gather(nxt, buf ^ 1);
-            const uint32_t m_nxt = nxt.m, eb_nxt = VAL ? nxt.eb : 0u;
-            int shift_nxt = 0;
-            floatx4 v_nxt = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (VAL) v_nxt = hidden_load_f32x4(a.edge_val + val_pos(m_nxt, eb_nxt, shift_nxt));
-            const int64_t tnn = tn + step;
-            // ids two tiles ahead; at the end of the run: the first tile of the caller's next run
-            const int64_t tfetch = !more ? tn /*unused: nxt already holds t_after's ids*/ : (tnn < te ? tnn : (t_after >= 0 ? t_after : t));
-            Ids nn;
-            request_ids(more ? tfetch : t, nn);
-            // ---- tile t
-            const uint32_t mb = (m_cur >> (8 * g)) & 0xffu;
-            half8 af;
-            if constexpr (VAL) {
-                const int nb = __popc(mb);
-                if (__builtin_expect(__any(nb + shift_cur > 4), 0)) {
-                    // rare: more than four edges of one row inside 8 columns, or the clamp at the end
-                    // of edge_val; ordinary loads (the compiler drains the queue for them)
-                    const int64_t e0 = (int64_t)eb_cur + __popc(m_cur & ((1u << (8 * g)) - 1u));
+    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, floatx4 (&acc)[NT]) const {
+        half8 af;
+        if constexpr (VAL) {
+            const uint32_t mb = (cur.m >> (8 * g)) & 0xffu;
+            const floatx4 vals = __builtin_bit_cast(floatx4, q);
+            const int nb = __popc(mb);
+            if (__builtin_expect(__any(nb + cur.shift > 4), 0)) {
+                // rare: more than four edges of one row inside 8 columns, or the clamp at the end of
+                // edge_val; ordinary loads (the compiler drains the DMA queue for them)
+                const int64_t e0 = (int64_t)cur.eb + __popc(cur.m & ((1u << (8 * g)) - 1u));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const bool on = (mb >> j) & 1u;
-                        const float v = on ? a.edge_val[e0 + __popc(mb & ((1u << j) - 1u))] * sa : 0.0f;
-                        af[j] = to_half_rna(v);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = __popc(mb & ((1u << j) - 1u)) + shift_cur;
-                        const float v01 = (k & 1) ? v_cur[1] : v_cur[0];
-                        const float v23 = (k & 1) ? v_cur[3] : v_cur[2];
-                        const float v = (k & 2) ? v23 : v01;
-                        af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const bool on = (mb >> j) & 1u;
+                    const float v = on ? a.edge_val[e0 + __popc(mb & ((1u << j) - 1u))] * sa : 0.0f;
+                    af[j] = to_half_rna(v);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? (_Float16)1.0f : (_Float16)0.0f;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = __popc(mb & ((1u << j) - 1u)) + cur.shift;
+                    const float v01 = (k & 1) ? vals[1] : vals[0];
+                    const float v23 = (k & 1) ? vals[3] : vals[2];
+                    const float v = (k & 2) ? v23 : v01;
+                    af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
+                }
             }
-            const uint32_t tile = ring + buf * TILE_BYTES;
-            half4 lo[NT], hi[NT];
-#pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                lo[s] = hidden_lds_tr16(tile + roff[s][0]);
-                hi[s] = hidden_lds_tr16(tile + roff[s][1]);
-            }
-            wait_lgkm0();
-#pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                settle(lo[s]);
-                settle(hi[s]);
-                const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
-            }
-            // ---- everything requested above has had the whole tile to arrive
-            wait_vm0();
-            if constexpr (VAL) settle(v_nxt);
-            settle_ids(nn);
-            if (!more) {   // nxt holds the ids of t_after (requested one iteration ago, or in the prologue)
-                carry.ids = nxt;
-                carry.tile = t_after;
-                break;
-            }
-            t = tn; tn = tnn; buf ^= 1;
-            m_cur = m_nxt; eb_cur = eb_nxt; shift_cur = shift_nxt; v_cur = v_nxt;
-            nxt = nn;
+        } else {
+            af = __builtin_bit_cast(half8, q);   // table entry of this lane's adjacency byte
         }
+        half4 lo[NT], hi[NT];
+        lds_tr_block<NT, BUF * TILE_BYTES>(raddr, lo, hi);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
+        }
+    }
+
+    // One pipeline stage, tile t in tile buffer BUF.  On entry the DMA queue holds gather(t),
+    // [edge values(t)] and the metadata of the next tile; after ONE wait everything is read from LDS
+    // (ids of the next tile + A fragment or edge values of this one), the next gather, the next edge
+    // values and the metadata of the tile after that are issued, and tile t is multiplied underneath.
+    // Returns false when t was the last tile of the run.
+    template <int BUF>
+    __device__ __forceinline__ bool stage(int64_t& t, int64_t& tn, const int64_t te, const int64_t step, const int64_t t_after,
+                                          Cur& cur, floatx4 (&acc)[NT]) const {
+        wait_vm0();
+        uint32_t v[NIDS];
+        uintx4 q;
+        const uint32_t qaddr = VAL ? vpad + (uint32_t)lane * 16u : atab + (((cur.m >> (8 * g)) & 0xffu) << 4);
+        lds_ids_block<NIDS>(idaddr, v, qaddr, q);
+        const bool more = tn < te;
+        Cur nx;
+        nx.m = v[NT];
+        nx.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
+        nx.shift = 0;
+        const int64_t tnn = tn + step;
+        if (more) {
+            dma_gather<BUF ^ 1>(v);
+            if constexpr (VAL) dma_vals(nx);
+            const int64_t tf = tnn < te ? tnn : t_after;   // metadata two tiles ahead; at the end of the run: the caller's next run
+            if (tf >= 0) meta.dma(tf, pad);
+        }
+        multiply<BUF>(cur, q, acc);
+        cur = nx;
+        t = tn;
+        tn = tnn;
+        return more;
+    }
+
+    // acc += A(tiles t, t+step, ... < te) * X16 rows.  `pad_tile` is the tile whose metadata the pad
+    // holds (or has in flight) on entry, and on return; passing the caller's next run's first tile as
+    // t_after lets the last stage prefetch it.
+    __device__ __forceinline__ void walk(int64_t t, const int64_t te, const int64_t step, floatx4 (&acc)[NT], int64_t& pad_tile,
+                                         const int64_t t_after) const {
+        if (t >= te) return;
+        if (pad_tile != t) meta.dma(t, pad);
+        wait_vm0();
+        uint32_t v[NIDS];
+        uintx4 q;
+        lds_ids_block<NIDS>(idaddr, v, atab, q);   // (the 16-byte read is a dummy here)
+        Cur cur;
+        cur.m = v[NT];
+        cur.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
+        cur.shift = 0;
+        dma_gather<0>(v);
+        if constexpr (VAL) dma_vals(cur);
+        int64_t tn = t + step;
+        const int64_t tf = tn < te ? tn : t_after;
+        if (tf >= 0) meta.dma(tf, pad);
+        for (;;) {   // ping-pong over the two tile buffers: static LDS offsets, no register rotation
+            if (!stage<0>(t, tn, te, step, t_after, cur, acc)) break;
+            if (!stage<1>(t, tn, te, step, t_after, cur, acc)) break;
+        }
+        pad_tile = t_after;
     }
 };
 
+// (second launch-bound argument = waves per SIMD: keeps the register budget at 128 / 256 so the
+// accumulators are allocated as VGPRs - with the default budget hipcc split them into AGPRs and
+// spent 24 v_accvgpr_* moves per tile shuffling them)
 template <int NT, int WAVES, bool VAL>
-__global__ __launch_bounds__(WAVES * 64) void spmm_kernel(const SpmmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(const SpmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = NT * 1024;
     const int lane = threadIdx.x & 63;
@@ -512,10 +553,13 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_kernel(const SpmmArgs a) {
 #pragma unroll
     for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
     {
-        const TileWalker<NT, VAL> tw(a, smem + wave * (2 * TILE_BYTES), coloff, pow2f(ka));
-        typename TileWalker<NT, VAL>::Carry carry;
-        carry.tile = -1;
-        tw.walk(tb + wave, te, WAVES, acc, carry, -1);
+        using TW = TileWalker<NT, VAL>;
+        char* atab = smem + WAVES * TW::WAVE_LDS;
+        fill_afrag_table(atab);
+        __syncthreads();
+        const TW tw(a, smem + wave * TW::WAVE_LDS, atab, coloff, pow2f(ka));
+        int64_t pad_tile = -1;
+        tw.walk(tb + wave, te, WAVES, acc, pad_tile, -1);
     }
 
     // ---- combine the wavefronts' partial sums in a fixed order and store
@@ -602,7 +646,11 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
     const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f;
-    const TileWalker<NT, VAL> tw(a, smem + wave * (2 * TILE_BYTES), coloff, pow2f(ka));
+    using TW = TileWalker<NT, VAL>;
+    char* atab = smem + 4 * TW::WAVE_LDS;
+    fill_afrag_table(atab);
+    __syncthreads();
+    const TW tw(a, smem + wave * TW::WAVE_LDS, atab, coloff, pow2f(ka));
 
     const int gw = blockIdx.x * 4 + wave, gwn = gridDim.x * 4;
     for (int grp = gw; grp < b.ngroups; grp += gwn) {
@@ -619,8 +667,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
 #pragma unroll
             for (int s = 0; s < NT; ++s) acc[j][s] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
-        typename TileWalker<NT, VAL>::Carry carry;
-        carry.tile = -1;
+        int64_t pad_tile = -1;
         // run q = (range r, window j); its bounds are looked up one run ahead so the walk can prefetch
         // the ids of the next run's first tile while it finishes the current one
         uint32_t nend[MAXW];
@@ -645,7 +692,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
 #pragma unroll
                 for (int jj = MAXW - 1; jj > j; --jj)
                     if (wj[jj] >= 0 && end[jj] > done[jj]) t_after = tbj[jj] + done[jj];
-                tw.walk(tbj[j] + done[j], tbj[j] + end[j], 1, acc[j], carry, t_after);
+                tw.walk(tbj[j] + done[j], tbj[j] + end[j], 1, acc[j], pad_tile, t_after);
                 done[j] = end[j];
             }
         }
@@ -679,27 +726,21 @@ struct SddmmArgs {
     const uint32_t* hdr;
     float* ef;
     int32_t N, Nc, row_off, Dpad, stride;
+    const int32_t* rowptr;
 };
 
-__device__ __forceinline__ half8 hidden_load_h8(const void* p) {
-    floatx4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return __builtin_bit_cast(half8, v);
-}
-typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));   // a register tuple the asm constraints accept (HIP's uint4 is a struct)
-__device__ __forceinline__ uintx4 hidden_load_u32x4(const void* p) {
-    uintx4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-// KS = number of 32-wide k steps (D <= 32*KS <= 128).  The window rows (A operand) stay in
-// registers; the neighbour rows of the NEXT tile (both 16-column halves, 2*KS 16-byte loads per
-// lane) are requested before the current tile is multiplied, so a wavefront pays one memory
-// latency per 32 condensed columns instead of one per 16 (first version) - same hidden-load
-// discipline as TileWalker: requested and settled inside one iteration.
+// KS = number of 32-wide k steps (D <= 32*KS <= 128).  The 16 window rows (MFMA A operand) stay in
+// registers.  Neighbour rows are the B operand, which for X * X^T is contiguous per lane: lane
+// (i, g) needs halves 32*ks + 8g .. +7 of neighbour row i.  Each lane DMAs exactly those 16 bytes
+// (structured-buffer addressing: row id * pitch + offset formed by the hardware) into its own LDS
+// slot and reads the slot back - LDS is a per-lane landing pad, trivially conflict-free - so the
+// gather of the NEXT tile (both 16-column halves) is in flight while the current one is multiplied
+// and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
 template <int KS, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
+    constexpr int WAVE_LDS = 2 * BUF_BYTES + kPadBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -718,59 +759,62 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
 
-    struct Ids { uint32_t cid[2]; uintx4 m4, eb4; };
-    auto request_ids = [&](int64_t t, Ids& d) {
-        d.cid[0] = hidden_load_u32(a.cols + t * kWbCols + i);
-        d.cid[1] = hidden_load_u32(a.cols + t * kWbCols + 16 + i);
-        d.m4 = hidden_load_u32x4(a.mask + t * kWinRows + 4 * g);
-        d.eb4 = hidden_load_u32x4(a.ebase + t * kWinRows + 4 * g);
-    };
-    auto settle_ids = [&](Ids& d) { settle(d.cid[0]); settle(d.cid[1]); settle(d.m4); settle(d.eb4); };
-    auto request_b = [&](const Ids& d, half8 (&b)[2][KS]) {
+    int64_t t = tb + wave;
+    if (t >= te) return;   // (wave-uniform; no barrier follows)
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
+    const MetaSource meta(a.cols, a.mask, a.ebase, lane);
+    const uint32_t ring = (uint32_t)(uintptr_t)((LDS_AS char*)(smem + wave * WAVE_LDS));
+    const uint32_t pad = ring + 2 * BUF_BYTES;
+    // a lane whose k slice lies past Dpad fetches slice 0 instead (valid memory) and is zeroed at use
+    uint32_t boff[KS];
+    bool bok[KS];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            // a lane whose k slice lies past Dpad re-reads slice 0 (valid memory) and is zeroed at use
-            const _Float16* bp = a.x16 + (int64_t)d.cid[sub] * stride;
+    for (int ks = 0; ks < KS; ++ks) { bok[ks] = ks * 32 + 8 * g < a.Dpad; boff[ks] = bok[ks] ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u; }
+    const uint32_t idaddr[2] = {pad + (uint32_t)i * 4u, pad + 64u + (uint32_t)i * 4u};           // row ids of both halves
+    uint32_t qaddr[1 + 2 * KS];                                                                   // edge offsets, then my landing slots
+    qaddr[0] = pad + 192u + 16u * (uint32_t)g;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) b[sub][ks] = hidden_load_h8(bp + ((ks * 32 + 8 * g < a.Dpad) ? ks * 32 + 8 * g : 0));
-        }
-    };
-    auto settle_b = [&](half8 (&b)[2][KS]) {
+    for (int k = 0; k < 2 * KS; ++k) qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    const uint32_t m4addr = pad + 128u + 16u * (uint32_t)g;
+    // edges of this window live in ef[e_w0 .. ): 32-bit offsets from a wave-uniform base
+    const int64_t wrow = (int64_t)w * kWinRows;
+    const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
+    char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
+
+    auto dma_b = [&](const uint32_t* cid, int bufbase) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) settle(b[sub][ks]);
+            for (int ks = 0; ks < KS; ++ks)
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + bufbase + (sub * KS + ks) * 1024), 16,
+                                                            (int)cid[sub], (int)boff[ks], 0, 0, 0);
     };
-
-    int64_t t = tb + wave;
-    if (t >= te) return;
-    Ids cur, nxt;
-    half8 bcur[2][KS], bnxt[2][KS];
-    request_ids(t, cur);
-    wait_vm0();
-    settle_ids(cur);
-    request_b(cur, bcur);
-    int64_t tn = t + WAVES;
-    request_ids(tn < te ? tn : t, nxt);
-    wait_vm0();
-    settle_b(bcur);
-    settle_ids(nxt);
-    for (;;) {
+    struct Cur { uintx4 m4, eb4; };
+    auto stage = [&](auto BUFC, Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
+        constexpr int BUF = decltype(BUFC)::value;
+        wait_vm0();
+        uint32_t cid[2];
+        uintx4 m4n, q[1 + 2 * KS];
+        lds_ids_block<2>(idaddr, cid, m4addr, m4n);                // ids + masks of the next tile
+        lds_q_block<1 + 2 * KS, BUF * BUF_BYTES>(qaddr, q);        // its edge offsets, and this tile's operands
         const bool more = tn < te;
-        request_b(nxt, bnxt);                       // valid tile even when !more (clamped), result unused then
         const int64_t tnn = tn + WAVES;
-        Ids nn;
-        request_ids(tnn < te ? tnn : t, nn);
-        // ---- tile t
+        if (more) {
+            dma_b(cid, (BUF ^ 1) * BUF_BYTES);
+            if (tnn < te) meta.dma(tnn, pad);
+        }
+        // ---- tile tcur
         const uint32_t mm[4] = {cur.m4[0], cur.m4[1], cur.m4[2], cur.m4[3]};
         const uint32_t ee[4] = {cur.eb4[0], cur.eb4[1], cur.eb4[2], cur.eb4[3]};
-        auto half_tile = [&](const int sub, const half8 (&bsub)[KS]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
             const uint32_t anyrow = ((mm[0] | mm[1] | mm[2] | mm[3]) >> (16 * sub)) & 0xffffu;
             if (__any(anyrow != 0u)) {              // skip a 16-column half no edge lands in
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const half8 bf = (ks * 32 + 8 * g < a.Dpad) ? bsub[ks] : hz;
+                    const half8 bf = bok[ks] ? __builtin_bit_cast(half8, q[1 + sub * KS + ks]) : hz;
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf, acc, 0, 0, 0);
                 }
                 // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
@@ -778,24 +822,36 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_kernel(const SddmmArgs a) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     if ((mm[ii] >> bit) & 1u) {
-                        const int64_t e = (int64_t)ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
-                        a.ef[e] = acc[ii] * inv * inv;
+                        const uint32_t rel = (uint32_t)((int64_t)ee[ii] - e_w0) + (uint32_t)__popc(mm[ii] & ((1u << bit) - 1u));
+                        *reinterpret_cast<float*>(ef_w + (rel << 2)) = acc[ii] * inv * inv;
                     }
                 }
             }
-        };
-        half_tile(0, bcur[0]);
-        half_tile(1, bcur[1]);
-        wait_vm0();
-        settle_b(bnxt);
-        settle_ids(nn);
-        if (!more) break;
-        t = tn; tn = tnn;
-        cur = nxt; nxt = nn;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bcur[sub][ks] = bnxt[sub][ks];
+        }
+        cur.m4 = m4n;
+        cur.eb4 = q[0];
+        tcur = tn;
+        tn = tnn;
+        return more;
+    };
+
+    // prologue: metadata of the first tile, its operands, metadata of the second
+    meta.dma(t, pad);
+    wait_vm0();
+    Cur cur;
+    {
+        uint32_t cid[2];
+        uintx4 e4[1];
+        lds_ids_block<2>(idaddr, cid, m4addr, cur.m4);
+        lds_q_block<1, 0>(qaddr, e4);
+        cur.eb4 = e4[0];
+        dma_b(cid, 0);
+    }
+    int64_t tn = t + WAVES;
+    if (tn < te) meta.dma(tn, pad);
+    for (;;) {
+        if (!stage(std::integral_constant<int, 0>{}, cur, t, tn)) break;
+        if (!stage(std::integral_constant<int, 1>{}, cur, t, tn)) break;
     }
 }
 
@@ -886,7 +942,7 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restric
 // ------------------------------------------------------------------------------------------
 template <int NT, int WAVES, bool VAL>
 static hipError_t launch_spmm_one(const SpmmArgs& args, int nwin, int nchunks, hipStream_t stream) {
-    const size_t lds = (size_t)WAVES * 2 * NT * 1024;
+    const size_t lds = (size_t)WAVES * TileWalker<NT, VAL>::WAVE_LDS + 4096;
     hipLaunchKernelGGL((spmm_kernel<NT, WAVES, VAL>), dim3((unsigned)nwin, (unsigned)nchunks), dim3(WAVES * 64), lds, stream, args);
     return hipGetLastError();
 }
@@ -917,7 +973,7 @@ static constexpr int blocked_maxw(int nt, bool val) { return (nt <= 4 && !val) ?
 template <int NT, bool VAL>
 static hipError_t launch_blocked_one(const SpmmBlockedArgs& args, int nwg, int nchunks, hipStream_t stream) {
     constexpr int MAXW = blocked_maxw(NT, VAL);
-    const size_t lds = (size_t)4 * 2 * NT * 1024;
+    const size_t lds = (size_t)4 * TileWalker<NT, VAL>::WAVE_LDS + 4096;
     hipLaunchKernelGGL((spmm_blocked_kernel<NT, MAXW, VAL>), dim3((unsigned)nwg, (unsigned)nchunks), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
@@ -936,10 +992,10 @@ template <int WAVES>
 static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipStream_t stream) {
     const dim3 grid((unsigned)nwin), block(WAVES * 64);
     switch (ks) {
-        case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES>), grid, block, 0, stream, args); break;
-        case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES>), grid, block, 0, stream, args); break;
-        case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES>), grid, block, 0, stream, args); break;
-        case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES>), grid, block, 0, stream, args); break;
+        case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES>), grid, block, (size_t)WAVES * (4 * 1 * 1024 + kPadBytes), stream, args); break;
+        case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES>), grid, block, (size_t)WAVES * (4 * 2 * 1024 + kPadBytes), stream, args); break;
+        case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES>), grid, block, (size_t)WAVES * (4 * 3 * 1024 + kPadBytes), stream, args); break;
+        case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES>), grid, block, (size_t)WAVES * (4 * 4 * 1024 + kPadBytes), stream, args); break;
         default: hipLaunchKernelGGL((sddmm_wide_kernel<WAVES>), grid, block, 0, stream, args); break;
     }
     return hipGetLastError();
@@ -956,8 +1012,9 @@ static constexpr size_t kHdrBytes = 256;
 // slower than D = 64), so rows up to 128 B are padded to a power of two and longer ones to whole lines.
 static int x16_pitch(int dpad) {
     const int bytes = dpad * 2;
-    if (bytes <= 128) { int p = 32; while (p < bytes) p <<= 1; return p / 2; }
-    return round_up(bytes, 128) / 2;
+    int p = 32;
+    while (p < bytes) p <<= 1;   // power of two: 32 B .. 128 B inside one line, longer rows whole lines
+    return p / 2;
 }
 
 static size_t workspace_bytes_for(int32_t N, int32_t D) {
@@ -1014,7 +1071,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
-    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E};
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -1030,7 +1087,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         auto wgs = [&](int nt) {   // persistent grid: what is resident at once (LDS: 8*nt KB per workgroup; registers: 4 or 2 per CU)
             const int maxw = blocked_maxw(nt, d_val != nullptr);
             b.ngroups = (plan->nw_eff + maxw - 1) / maxw;
-            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, 160 / (8 * nt)));
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, 160 / (8 * nt + 10)));
             return std::min((b.ngroups + 3) / 4, plan->num_cus * per_cu);
         };
         if (nfull) { b.base.chunk0 = 0; const int n = wgs(8); HIP_TRY(launch_blocked_any(d_val != nullptr, 8, b, n, nfull, stream)); }
@@ -1226,7 +1283,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream);
     hipError_t e = plan->waves == 4 ? launch_sddmm_ks<4>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1>(ks, a, plan->nw_eff, stream);

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtcgnn_hip.so")
+LIB_PATH = os.environ.get("TCGNN_LIB_PATH") or os.path.join(_HERE, "lib", "libtcgnn_hip.so")  # override: A/B builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Audit of the gfx950 assembly for the hidden-load discipline of tcgnn_device.hip.
+
+A load issued from inline asm is invisible to hipcc's waitcnt bookkeeping: nothing may read (or
+copy, or overwrite) its destination VGPRs until OUR s_waitcnt has retired it.  This script walks
+every kernel's listing in program order and reports any instruction that touches a VGPR with such
+a load in flight (global_load_* / ds_read_* inside ;;#ASMSTART .. ;;#ASMEND) before the covering
+s_waitcnt vmcnt(0) / lgkmcnt(0).  Straight-line approximation: labels are treated as fall-through,
+which is exact for the loops in this file (every back-edge is preceded by a full wait).
+usage: audit_hidden_loads.py file.s [kernel-substring]
+"""
+import re, sys
+
+def regs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(3) is not None: out.add(int(m.group(3)))
+        else: out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+def audit(path, filt=""):
+    kernel, in_asm, vm, lgkm, bad = None, False, {}, {}, 0
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        m = re.match(r"^(_Z\w+):", s)
+        if m: kernel, vm, lgkm = m.group(1), {}, {}; continue
+        if kernel is None or filt not in kernel: continue
+        if s.startswith(";;#ASMSTART"): in_asm = True; continue
+        if s.startswith(";;#ASMEND"): in_asm = False; continue
+        if not s or s.startswith((";", ".")): continue
+        op = s.split()[0]
+        if op == "s_endpgm": kernel = None; continue
+        if op == "s_waitcnt":
+            if "vmcnt(0)" in s: vm = {}
+            if "lgkmcnt(0)" in s: lgkm = {}
+            continue
+        ops = s[len(op):].split(";")[0]
+        parts = [p.strip() for p in ops.split(",")]
+        touched = regs(ops)
+        hit = [r for r in touched if r in vm or r in lgkm]
+        is_hidden_load = in_asm and (op.startswith("global_load") or op.startswith("ds_read"))
+        if hit and not (is_hidden_load and set(hit) <= regs(parts[0]) and not (regs(",".join(parts[1:])) & set(hit))):
+            print("%s:%d  %s\n    touches v%s with a hidden load in flight (issued at line %s)" % (kernel[:60], ln, s, sorted(hit), [vm.get(r, lgkm.get(r)) for r in sorted(hit)]))
+            bad += 1
+        if is_hidden_load:
+            (vm if op.startswith("global_load") else lgkm).update({r: ln for r in regs(parts[0])})
+    return bad
+
+if __name__ == "__main__":
+    n = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    print("violations:", n)
+    sys.exit(1 if n else 0)
