@@ -144,6 +144,12 @@ def single_gpu(args):
     gteps = E / (elapsed / args.steps) / 1e9
     workload = "%s-shape synthetic graph N=%d nnz=%d, SpMM D=%d (GCN aggregation, fwd = bwd)" % (args.shape, n, E, D)
     roof_b = spmm_bytes(n, E, D)
+    nt = min(8, (D + 15) // 16)
+    pitch = 16
+    while pitch < ((D + 15) // 16) * 16:
+        pitch *= 2
+    blocked = info["column_buckets"] > 0 and (n + 1) * pitch * 2 > (6 << 20)   # the launcher's rule (tcgnn_device.hip run_spmm)
+    kname = ("spmm_blocked_kernel<NT=%d,MAXW=%d>" % (nt, 4 if nt <= 4 else 2)) if blocked else ("spmm_kernel<NT=%d,WAVES=%d>" % (nt, info["waves_per_window"]))
     out = {
         "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
         "value": round(gteps, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -152,9 +158,9 @@ def single_gpu(args):
         "config": {"workload": workload, "graph": "seeded uniform symmetric, canonical CSR", "tc_blocks_16x8": info["tc_blocks"],
                    "reddit_real_tc_blocks_16x8": 13566510, "wide_blocks_16x32": info["wide_blocks"],
                    "waves_per_window": info["waves_per_window"], "parallelism": "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": "spmm_kernel<NT=%d,WAVES=%d>" % ((D + 15) // 16 if D <= 128 else 8, info["waves_per_window"]),
+        "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": load_traffic("spmm_kernel", "%s_d%d" % (args.shape, D)),
+                     "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": load_traffic(kname.split("<")[0], "%s_d%d" % (args.shape, D)),
                      "algorithmic_bytes": roof_b, "kernel_ms_mean": round(k_mean, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if kernel_ms else None,
                      "kernel_launches_timed": len(kernel_ms)},
     }

@@ -66,6 +66,8 @@ typedef struct tcgnn_plan_info {
     int64_t plan_bytes;      /* device bytes owned by the plan */
     int32_t canonical;       /* 1 if every CSR row is strictly increasing (scipy canonical form) */
     int32_t waves_per_window;/* workgroup shape the launcher picked (1 or 4 wavefronts) */
+    int32_t column_buckets;  /* > 0: the plan carries the bucket table of the range-blocked SpMM walk */
+    int32_t reserved;
 } tcgnn_plan_info;
 
 int tcgnn_abi_version(void);

@@ -1004,7 +1004,8 @@ static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipSt
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
-static constexpr size_t kRangeTargetBytes = 2u << 20;  // X16 bytes per column range (4 MB L2 per XCD)
+static constexpr size_t kRangeTargetBytes = 1u << 20;  // X16 bytes per column range: wavefronts drift by a range or two
+                                                        // and the 4 MB L2 also streams metadata (sweep: 0.5-1.5 MB best at D=64)
 static constexpr size_t kHdrBytes = 256;
 
 // Row pitch of the fp16 image in halves: a gathered row should touch as few 128-byte lines as
@@ -1084,10 +1085,13 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         int nranges = 1;
         while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
         SpmmBlockedArgs b{a, plan->d_bptr, plan->nbuckets, plan->nbuckets / nranges, nranges, plan->nw_eff, 0};
-        auto wgs = [&](int nt) {   // persistent grid: what is resident at once (LDS: 8*nt KB per workgroup; registers: 4 or 2 per CU)
-            const int maxw = blocked_maxw(nt, d_val != nullptr);
+        auto wgs = [&](int nt) {   // persistent grid = what is resident at once: LDS per workgroup (4 wavefronts: tile buffers,
+                                   // pads, + the 4 KB A table) against 160 KB, and the register budget (4 or 2 workgroups per CU)
+            const bool val = d_val != nullptr;
+            const int maxw = blocked_maxw(nt, val);
             b.ngroups = (plan->nw_eff + maxw - 1) / maxw;
-            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, 160 / (8 * nt + 10)));
+            const int lds_wg = 4 * (2 * nt * 1024 + kPadBytes + (val ? 1024 : 0)) + 4096;
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, (160 * 1024) / lds_wg));
             return std::min((b.ngroups + 3) / 4, plan->num_cus * per_cu);
         };
         if (nfull) { b.base.chunk0 = 0; const int n = wgs(8); HIP_TRY(launch_blocked_any(d_val != nullptr, 8, b, n, nfull, stream)); }
@@ -1220,6 +1224,7 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
     info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
     info->canonical = plan->canonical; info->waves_per_window = plan->waves;
+    info->column_buckets = plan->nbuckets; info->reserved = 0;
     return TCGNN_OK;
 }
 
