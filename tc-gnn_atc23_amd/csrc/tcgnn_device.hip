@@ -539,7 +539,6 @@ struct TileWalker {
 template <int NT, int WAVES, bool VAL>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(const SpmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_BYTES = NT * 1024;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -637,7 +636,6 @@ __global__ void bucket_ptr_kernel(const int64_t* __restrict__ wb_ptr, const int3
 template <int NT, int MAXW, bool VAL>
 __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(const SpmmBlockedArgs b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_BYTES = NT * 1024;
     const SpmmArgs& a = b.base;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -727,6 +725,8 @@ struct SddmmArgs {
     float* ef;
     int32_t N, Nc, row_off, Dpad, stride;
     const int32_t* rowptr;
+    const uint32_t* bptr;       // range-blocked walk (nranges > 0)
+    int32_t nbuckets, gsel, nranges, nw;
 };
 
 // KS = number of 32-wide k steps (D <= 32*KS <= 128).  The 16 window rows (MFMA A operand) stay in
@@ -736,7 +736,7 @@ struct SddmmArgs {
 // slot and reads the slot back - LDS is a per-lane landing pad, trivially conflict-free - so the
 // gather of the NEXT tile (both 16-column halves) is in flight while the current one is multiplied
 // and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
-template <int KS, int WAVES>
+template <int KS, int WAVES, bool BLOCKED>
 __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
@@ -744,23 +744,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
-    const int w = a.order[blockIdx.x];
-    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
     const int64_t stride = a.stride;
     const int kx = scale_exp_from_bits(a.hdr[0]);
-    const float inv = pow2f(-kx);
+    // ef = acc * 2^(-2kx); one multiply unless 2kx leaves the fp32 exponent range (then two)
+    const bool two_step = kx > 63 || kx < -63;
+    const float inv_a = two_step ? pow2f(-kx) : pow2f(-2 * kx), inv_b = two_step ? pow2f(-kx) : 1.0f;
     const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
-    int64_t arow = (int64_t)w * kWinRows + i;
-    arow = arow < a.N ? arow + a.row_off : a.Nc;
-    const _Float16* ap = a.x16 + arow * stride + 8 * g;
-    half8 af[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-
-    int64_t t = tb + wave;
-    if (t >= te) return;   // (wave-uniform; no barrier follows)
+    const uint32_t below[2] = {(1u << i) - 1u, (1u << (16 + i)) - 1u};   // condensed columns left of mine, per half
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
     const MetaSource meta(a.cols, a.mask, a.ebase, lane);
@@ -777,6 +767,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
 #pragma unroll
     for (int k = 0; k < 2 * KS; ++k) qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
     const uint32_t m4addr = pad + 128u + 16u * (uint32_t)g;
+
+  // one run: tiles t, t+step, ... < te of window w
+  auto run = [&](const int w, int64_t t, const int64_t te, const int64_t step) {
+    if (t >= te) return;
+    // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
+    int64_t arow = (int64_t)w * kWinRows + i;
+    arow = arow < a.N ? arow + a.row_off : a.Nc;
+    const _Float16* ap = a.x16 + arow * stride + 8 * g;
+    half8 af[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
     // edges of this window live in ef[e_w0 .. ): 32-bit offsets from a wave-uniform base
     const int64_t wrow = (int64_t)w * kWinRows;
     const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
@@ -799,14 +800,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
         lds_ids_block<2>(idaddr, cid, m4addr, m4n);                // ids + masks of the next tile
         lds_q_block<1 + 2 * KS, BUF * BUF_BYTES>(qaddr, q);        // its edge offsets, and this tile's operands
         const bool more = tn < te;
-        const int64_t tnn = tn + WAVES;
+        const int64_t tnn = tn + step;
         if (more) {
             dma_b(cid, (BUF ^ 1) * BUF_BYTES);
             if (tnn < te) meta.dma(tnn, pad);
         }
         // ---- tile tcur
         const uint32_t mm[4] = {cur.m4[0], cur.m4[1], cur.m4[2], cur.m4[3]};
-        const uint32_t ee[4] = {cur.eb4[0], cur.eb4[1], cur.eb4[2], cur.eb4[3]};
+        const uint32_t e0 = (uint32_t)e_w0;   // window-relative edge positions (a window holds far fewer than 2^32 edges)
+        const uint32_t rbase[4] = {cur.eb4[0] - e0, cur.eb4[1] - e0, cur.eb4[2] - e0, cur.eb4[3] - e0};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const uint32_t anyrow = ((mm[0] | mm[1] | mm[2] | mm[3]) >> (16 * sub)) & 0xffffu;
@@ -814,16 +816,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const half8 bf = bok[ks] ? __builtin_bit_cast(half8, q[1 + sub * KS + ks]) : hz;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf, acc, 0, 0, 0);
+                    // (a lane whose k slice lies past Dpad holds zeros in af: whatever it fetched for B is multiplied away)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], __builtin_bit_cast(half8, q[1 + sub * KS + ks]), acc, 0, 0, 0);
                 }
                 // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
                 const int bit = 16 * sub + i;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     if ((mm[ii] >> bit) & 1u) {
-                        const uint32_t rel = (uint32_t)((int64_t)ee[ii] - e_w0) + (uint32_t)__popc(mm[ii] & ((1u << bit) - 1u));
-                        *reinterpret_cast<float*>(ef_w + (rel << 2)) = acc[ii] * inv * inv;
+                        const uint32_t rel = rbase[ii] + (uint32_t)__popc(mm[ii] & below[sub]);
+                        float v = acc[ii] * inv_a;
+                        if (two_step) v *= inv_b;
+                        *reinterpret_cast<float*>(ef_w + (rel << 2)) = v;
                     }
                 }
             }
@@ -847,11 +851,29 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
         cur.eb4 = e4[0];
         dma_b(cid, 0);
     }
-    int64_t tn = t + WAVES;
+    int64_t tn = t + step;
     if (tn < te) meta.dma(tn, pad);
     for (;;) {
         if (!stage(std::integral_constant<int, 0>{}, cur, t, tn)) break;
         if (!stage(std::integral_constant<int, 1>{}, cur, t, tn)) break;
+    }
+    wait_vm0();   // the run's last stores are retired before the next run reuses pad and slots
+  };
+
+    if constexpr (BLOCKED) {
+        // persistent wavefronts take (column range, window) items in range-major order: at any moment
+        // the whole chip gathers from one or two ranges of X16, which stay L2-resident
+        const int64_t items = (int64_t)a.nranges * a.nw;
+        for (int64_t q = (int64_t)blockIdx.x * WAVES + wave; q < items; q += (int64_t)gridDim.x * WAVES) {
+            const int r = (int)(q / a.nw);
+            const int w = __builtin_amdgcn_readfirstlane(a.order[q - (int64_t)r * a.nw]);
+            const int64_t tb = a.wb_ptr[w];
+            const uint32_t* bp = a.bptr + (int64_t)w * (a.nbuckets + 1);
+            run(w, tb + bp[r * a.gsel], tb + bp[(r + 1) * a.gsel], 1);
+        }
+    } else {
+        const int w = a.order[blockIdx.x];
+        run(w, a.wb_ptr[w] + wave, a.wb_ptr[w + 1], WAVES);
     }
 }
 
@@ -988,14 +1010,15 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
 #undef TCGNN_BLK_CASE
 }
 
-template <int WAVES>
-static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwin, hipStream_t stream) {
-    const dim3 grid((unsigned)nwin), block(WAVES * 64);
+template <int WAVES, bool BLOCKED>
+static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwg, hipStream_t stream) {
+    const dim3 grid((unsigned)nwg), block(WAVES * 64);
+    const size_t lds = (size_t)WAVES * (4 * (ks <= 4 ? ks : 1) * 1024 + kPadBytes);
     switch (ks) {
-        case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES>), grid, block, (size_t)WAVES * (4 * 1 * 1024 + kPadBytes), stream, args); break;
-        case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES>), grid, block, (size_t)WAVES * (4 * 2 * 1024 + kPadBytes), stream, args); break;
-        case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES>), grid, block, (size_t)WAVES * (4 * 3 * 1024 + kPadBytes), stream, args); break;
-        case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES>), grid, block, (size_t)WAVES * (4 * 4 * 1024 + kPadBytes), stream, args); break;
+        case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
+        case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
+        case 3: hipLaunchKernelGGL((sddmm_kernel<3, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
+        case 4: hipLaunchKernelGGL((sddmm_kernel<4, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
         default: hipLaunchKernelGGL((sddmm_wide_kernel<WAVES>), grid, block, 0, stream, args); break;
     }
     return hipGetLastError();
@@ -1288,10 +1311,29 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream);
-    hipError_t e = plan->waves == 4 ? launch_sddmm_ks<4>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1>(ks, a, plan->nw_eff, stream);
+    const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
+    // measured on the Reddit shape: the range-major walk is bit-identical but 15-20 % slower for SDDMM (its loop is
+    // bound by the scatter and the per-tile latency chain, not by gather locality) - only on request (mode 2)
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0;
+    hipError_t e;
+    if (blocked) {
+        size_t range_bytes = 2 * kRangeTargetBytes;   // no accumulators to keep: longer runs, fewer restarts
+        if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
+        int nranges = 1;
+        while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
+        a.nranges = nranges;
+        a.gsel = plan->nbuckets / nranges;
+        const int lds_wg = 4 * (4 * ks * 1024 + kPadBytes);
+        const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds_wg));
+        const int64_t items = (int64_t)nranges * plan->nw_eff;
+        const int nwg = (int)std::min<int64_t>((items + 3) / 4, (int64_t)plan->num_cus * per_cu);
+        e = launch_sddmm_ks<4, true>(ks, a, nwg, stream);
+    } else {
+        e = plan->waves == 4 ? launch_sddmm_ks<4, false>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1, false>(ks, a, plan->nw_eff, stream);
+    }
     HIP_TRY(e);
     return TCGNN_OK;
 }
