@@ -1,0 +1,33 @@
+"""Build-time guarantees of the HIP kernels that can be checked without a GPU."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generated_lds_blocks_are_up_to_date(tmp_path):
+    inc = os.path.join(ROOT, "tc-gnn_atc23_amd", "csrc", "tcgnn_lds_blocks.inc")
+    before = open(inc).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_lds_blocks.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before, "tcgnn_lds_blocks.inc differs from what tools/gen_lds_blocks.py generates"
+
+
+def test_isa_audit_no_inflight_register_is_touched_and_nothing_spills(tmp_path):
+    """Compiles tcgnn_device.hip for gfx950 with -save-temps and runs tools/audit_hidden_loads.py over
+    the listing: every inline-asm load must be waited for inside its own asm statement (or before any
+    instruction reads/overwrites its destination), and no kernel may use scratch."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tc-gnn_atc23_amd", "csrc"), "audit", "AUDIT_DIR=%s" % tmp_path],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "violations: 0" in r.stdout
+
+
+def test_audit_script_detects_a_planted_violation(tmp_path):
+    s = tmp_path / "bad.s"
+    s.write_text("_Zbad:\n;;#ASMSTART\n\tglobal_load_dword v3, v1, s[2:3]\n;;#ASMEND\n\tv_mov_b32_e32 v2, v3\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_hidden_loads.py"), str(s)], capture_output=True, text=True)
+    assert r.returncode == 1 and "violations: 1" in r.stdout
+    s.write_text("_Zok:\n;;#ASMSTART\n\tds_read_b32 v3, v1\n\ts_waitcnt lgkmcnt(0)\n;;#ASMEND\n\tv_mov_b32_e32 v2, v3\n\ts_endpgm\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_hidden_loads.py"), str(s)], capture_output=True, text=True)
+    assert r.returncode == 0
