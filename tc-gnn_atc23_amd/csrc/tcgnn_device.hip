@@ -304,6 +304,11 @@ typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
 #include "tcgnn_lds_blocks.inc"
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS store issued from asm (no destination register, so nothing can be in flight into a VGPR);
+// LDS operations of one wavefront execute in order, a later block read sees the data.
+__device__ __forceinline__ void lds_write_b32(uint32_t lds_byte_addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
+}
 
 template <int N> __device__ __forceinline__ void lds_ids_block(const uint32_t* ad, uint32_t* v, uint32_t qaddr, uintx4& q) {
     if constexpr (N == 1) lds_ids_block1(ad, v, qaddr, q);
@@ -729,6 +734,14 @@ struct SddmmArgs {
     int32_t nbuckets, gsel, nranges, nw;
 };
 
+// LDS of one SDDMM wavefront: two operand buffers, the metadata pad, the output staging area
+// (16 rows x kSddmmStageCap floats) and 256 bytes of junk slots for lanes that have nothing to stage.
+static constexpr int kSddmmStageCap = 64;
+// Operand buffers: two (gather of the next tile under the multiply of this one) up to D = 64; one beyond,
+// where LDS would otherwise allow a single workgroup per CU (latency is then hidden by wavefront count only).
+static constexpr int sddmm_nbuf(int ks) { return ks <= 2 ? 2 : 1; }
+static constexpr int sddmm_wave_lds(int ks) { return sddmm_nbuf(ks) * (2 * ks * 1024) + kPadBytes + 16 * kSddmmStageCap * 4 + 256; }
+
 // KS = number of 32-wide k steps (D <= 32*KS <= 128).  The 16 window rows (MFMA A operand) stay in
 // registers.  Neighbour rows are the B operand, which for X * X^T is contiguous per lane: lane
 // (i, g) needs halves 32*ks + 8g .. +7 of neighbour row i.  Each lane DMAs exactly those 16 bytes
@@ -737,10 +750,11 @@ struct SddmmArgs {
 // gather of the NEXT tile (both 16-column halves) is in flight while the current one is multiplied
 // and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
 template <int KS, int WAVES, bool BLOCKED>
-__global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(const SddmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
-    constexpr int WAVE_LDS = 2 * BUF_BYTES + kPadBytes;
+    constexpr int WAVE_LDS = sddmm_wave_lds(KS);
+    constexpr int CAP = kSddmmStageCap;                    // staged outputs per row before a flush
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
     const MetaSource meta(a.cols, a.mask, a.ebase, lane);
     const uint32_t ring = (uint32_t)(uintptr_t)((LDS_AS char*)(smem + wave * WAVE_LDS));
-    const uint32_t pad = ring + 2 * BUF_BYTES;
+    const uint32_t pad = ring + sddmm_nbuf(KS) * BUF_BYTES;
     // a lane whose k slice lies past Dpad fetches slice 0 instead (valid memory) and is zeroed at use
     uint32_t boff[KS];
     bool bok[KS];
@@ -767,8 +781,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
 #pragma unroll
     for (int k = 0; k < 2 * KS; ++k) qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
     const uint32_t m4addr = pad + 128u + 16u * (uint32_t)g;
+    // Output staging.  PMC (profiles/r01): scattering every result with its own 4-byte store costs
+    // 7.6e7 L2 write requests per launch on top of the 1.25e8 gather reads, and the kernel runs at the
+    // L2 request-rate ceiling.  A wavefront walks CONSECUTIVE tiles, and a row's edges in consecutive
+    // tiles are consecutive in ef, so results are staged per row in LDS and each row is flushed as one
+    // contiguous store (about one store per tile instead of eight, ~10x fewer write requests).
+    const uint32_t stg = pad + kPadBytes;
+    const uint32_t junk = stg + 16u * CAP * 4u + (uint32_t)lane * 4u;
+    const uint32_t stg_row[4] = {stg + (uint32_t)(4 * g + 0) * CAP * 4u, stg + (uint32_t)(4 * g + 1) * CAP * 4u,
+                                 stg + (uint32_t)(4 * g + 2) * CAP * 4u, stg + (uint32_t)(4 * g + 3) * CAP * 4u};
+    const uint32_t flush_base = stg + (uint32_t)lane * 4u;        // lane j reads the j-th staged result of every row
 
-  // one run: tiles t, t+step, ... < te of window w
+  // one run: CONSECUTIVE tiles t .. te-1 of window w (step must be 1: the staging relies on it)
   auto run = [&](const int w, int64_t t, const int64_t te, const int64_t step) {
     if (t >= te) return;
     // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
@@ -782,6 +806,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
     const int64_t wrow = (int64_t)w * kWinRows;
     const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
     char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};                          // staged results of rows 4g .. 4g+3
+    uint32_t rstart[4] = {~0u, ~0u, ~0u, ~0u};                   // window-relative ef position of each row's first staged result
+    auto flush = [&]() {
+        uint32_t vals[16];
+        lds_rows_block8<CAP * 4, 0>(flush_base, vals);
+        lds_rows_block8<CAP * 4, 8>(flush_base, vals + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt[r & 3], 16 * (r >> 2));
+            const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart[r & 3], 16 * (r >> 2));
+            if ((uint32_t)lane < c_r) *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) { cnt[ii] = 0u; rstart[ii] = ~0u; }
+    };
 
     auto dma_b = [&](const uint32_t* cid, int bufbase) {
 #pragma unroll
@@ -798,11 +837,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
         uint32_t cid[2];
         uintx4 m4n, q[1 + 2 * KS];
         lds_ids_block<2>(idaddr, cid, m4addr, m4n);                // ids + masks of the next tile
-        lds_q_block<1 + 2 * KS, BUF * BUF_BYTES>(qaddr, q);        // its edge offsets, and this tile's operands
+        constexpr int NB = sddmm_nbuf(KS);
+        lds_q_block<1 + 2 * KS, (NB == 2 ? BUF : 0) * BUF_BYTES>(qaddr, q);   // its edge offsets, and this tile's operands
         const bool more = tn < te;
         const int64_t tnn = tn + step;
         if (more) {
-            dma_b(cid, (BUF ^ 1) * BUF_BYTES);
+            dma_b(cid, (NB == 2 ? (BUF ^ 1) : 0) * BUF_BYTES);   // (single buffer: its reads above have completed)
             if (tnn < te) meta.dma(tnn, pad);
         }
         // ---- tile tcur
@@ -819,19 +859,26 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
                     // (a lane whose k slice lies past Dpad holds zeros in af: whatever it fetched for B is multiplied away)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], __builtin_bit_cast(half8, q[1 + sub * KS + ks]), acc, 0, 0, 0);
                 }
-                // C[row 4g+ii][col i] -> edge (row, condensed column 16*sub+i) if present
+                // C[row 4g+ii][col i] -> staged at the row's next free slot if the edge exists
                 const int bit = 16 * sub + i;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    if ((mm[ii] >> bit) & 1u) {
-                        const uint32_t rel = rbase[ii] + (uint32_t)__popc(mm[ii] & below[sub]);
-                        float v = acc[ii] * inv_a;
-                        if (two_step) v *= inv_b;
-                        *reinterpret_cast<float*>(ef_w + (rel << 2)) = v;
-                    }
+                    const bool on = (mm[ii] >> bit) & 1u;
+                    const uint32_t pos = cnt[ii] + (uint32_t)__popc(mm[ii] & below[sub]);
+                    float v = acc[ii] * inv_a;
+                    if (two_step) v *= inv_b;
+                    lds_write_b32(on ? stg_row[ii] + (pos << 2) : junk, v);
                 }
             }
         }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            if (rstart[ii] == ~0u && mm[ii] != 0u) rstart[ii] = rbase[ii];
+            cnt[ii] += (uint32_t)__popc(mm[ii]);
+        }
+        // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
+        const uint32_t fullest = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+        if (!more || __any(fullest > (uint32_t)(CAP - 32))) flush();
         cur.m4 = m4n;
         cur.eb4 = q[0];
         tcur = tn;
@@ -873,7 +920,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sddmm_kernel(const SddmmArgs a)
         }
     } else {
         const int w = a.order[blockIdx.x];
-        run(w, a.wb_ptr[w] + wave, a.wb_ptr[w + 1], WAVES);
+        const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+        const int64_t chunk = (te - tb + WAVES - 1) / WAVES;       // contiguous share of this wavefront
+        const int64_t t0 = tb + wave * chunk;
+        run(w, t0, t0 + chunk < te ? t0 + chunk : te, 1);
     }
 }
 
@@ -1013,7 +1063,7 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
 template <int WAVES, bool BLOCKED>
 static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwg, hipStream_t stream) {
     const dim3 grid((unsigned)nwg), block(WAVES * 64);
-    const size_t lds = (size_t)WAVES * (4 * (ks <= 4 ? ks : 1) * 1024 + kPadBytes);
+    const size_t lds = (size_t)WAVES * sddmm_wave_lds(ks <= 4 ? ks : 1);
     switch (ks) {
         case 1: hipLaunchKernelGGL((sddmm_kernel<1, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
         case 2: hipLaunchKernelGGL((sddmm_kernel<2, WAVES, BLOCKED>), grid, block, lds, stream, args); break;
@@ -1315,18 +1365,19 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream);
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    // measured on the Reddit shape: the range-major walk is bit-identical but 15-20 % slower for SDDMM (its loop is
-    // bound by the scatter and the per-tile latency chain, not by gather locality) - only on request (mode 2)
-    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0;
+    // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
+    // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
+    // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || x16_bytes > kBlockedMinBytes);
     hipError_t e;
     if (blocked) {
-        size_t range_bytes = 2 * kRangeTargetBytes;   // no accumulators to keep: longer runs, fewer restarts
+        size_t range_bytes = 4 * kRangeTargetBytes;
         if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
         int nranges = 1;
         while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
         a.nranges = nranges;
         a.gsel = plan->nbuckets / nranges;
-        const int lds_wg = 4 * (4 * ks * 1024 + kPadBytes);
+        const int lds_wg = 4 * sddmm_wave_lds(ks);
         const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds_wg));
         const int64_t items = (int64_t)nranges * plan->nw_eff;
         const int nwg = (int)std::min<int64_t>((items + 3) / 4, (int64_t)plan->num_cus * per_cu);

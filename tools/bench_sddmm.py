@@ -23,5 +23,5 @@ for D in (64, 16, 32, 128):
         for _ in range(8): y = TCGNN.forward_ef(X, *meta)[0]
         res[(mode, kb)] = (np.median(TCGNN.kernel_timing(*meta)), y)
     ref = res[(1, 0)][1]
-    print("D=%3d  " % D + "  ".join("%s %.3f ms (diff %.1e)" % ("plain" if m == 1 else "blocked/%dK" % kb, t, (y - ref).abs().max().item()) for (m, kb), (t, y) in res.items()))
+    print("D=%3d  " % D + "  ".join("%s %.3f" % ("plain" if m == 1 else "b/%dK" % kb, t) for (m, kb), (t, y) in res.items()) + "  maxdiff %.1e" % max((y - ref).abs().max().item() for _, (t, y) in res.items()))
 c.lib.tcgnn_set_spmm_mode(0)
