@@ -99,6 +99,24 @@ int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_nodePointer
                          int32_t* d_edgeToColumn, int32_t* d_edgeToRow, int64_t* tc_blocks,
                          void* stream);
 
+/* Tile statistics of the translation - what the reference's counting scripts report
+ * (3_cnt_TC_blk_SpMM.py:38-94 with 16x8 tiles, 3_cnt_TC_blk_SDDMM.py with 16x16; logs/16x8_reduction.csv,
+ * logs/reduce_blocks.csv): per window of tile_h rows, U = sorted unique neighbour ids;
+ * condensed tiles = ceil(|U|/tile_w), sliding tiles = greedy cover of U by intervals of tile_w ids.
+ * HOST pointers; rows need not be sorted.  num_threads <= 0 means "all hardware threads". */
+typedef struct tcgnn_tile_stats_t {
+    int64_t windows;                 /* ceil(N / tile_h) */
+    int64_t nonempty_windows;
+    int64_t edges;                   /* nnz of the CSR (duplicates included) */
+    int64_t unique_columns;          /* sum over windows of |U| */
+    int64_t sliding_tiles;           /* the scripts' "origin" column */
+    int64_t condensed_tiles;         /* the scripts' "reduced" column */
+    int64_t max_sliding_per_window;
+    int64_t max_condensed_per_window;
+} tcgnn_tile_stats_t;
+int tcgnn_tile_stats(const int32_t* edgeList, const int32_t* nodePointer, int32_t num_nodes,
+                     int32_t tile_h, int32_t tile_w, tcgnn_tile_stats_t* out, int32_t num_threads);
+
 /* ---- plan: legacy metadata -> packed tile stream (device) --------------------------------- */
 
 /* Builds the packed tile stream on the device from the five legacy arrays every reference entry

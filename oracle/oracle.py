@@ -155,6 +155,26 @@ def round_fp16(x):
 
 # ------------------------------------------------------------------ compiled reference (oracle/_ref)
 
+def tile_counts(rowptr, col, tile_h=16, tile_w=8):
+    """(sliding, condensed) tile counts as 3_cnt_TC_blk_SpMM.py:56-81 computes them (pure Python, small graphs):
+    per window of tile_h rows, the sorted set of neighbour ids; condensed = ceil(|set| / tile_w) (:66);
+    sliding = greedy walk placing a tile of tile_w ids at the first uncovered id (:72-81)."""
+    rowptr = np.asarray(rowptr); col = np.asarray(col)
+    n = len(rowptr) - 1
+    sliding = condensed = 0
+    for w0 in range(0, n, tile_h):
+        ids = sorted(set(int(c) for c in col[rowptr[w0]:rowptr[min(w0 + tile_h, n)]]))
+        condensed += (len(ids) + tile_w - 1) // tile_w
+        i = j = 0
+        while i < len(ids) and j < len(ids):
+            end = ids[i] + tile_w
+            while j < len(ids) and ids[j] < end:
+                j += 1
+            i = j
+            sliding += 1
+    return sliding, condensed
+
+
 def ref_available():
     return bool(glob.glob(os.path.join(_HERE, "_ref", "TCGNN_ref*.so")))
 

@@ -193,4 +193,70 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
     return TCGNN_OK;
 }
 
+// Tile statistics of the sparse-graph translation (what 3_cnt_TC_blk_SpMM.py:38-94 / 3_cnt_TC_blk_SDDMM.py count
+// with Python sets): per window of tile_h rows take the sorted unique neighbour ids U;
+//   condensed tiles = ceil(|U| / tile_w)                                  (3_cnt_TC_blk_SpMM.py:66)
+//   sliding tiles   = greedy cover of U by intervals [u, u + tile_w)      (3_cnt_TC_blk_SpMM.py:72-81)
+int tcgnn_tile_stats(const int32_t* edgeList, const int32_t* nodePointer, int32_t num_nodes, int32_t tile_h, int32_t tile_w,
+                     tcgnn_tile_stats_t* out, int32_t num_threads) {
+    if (!nodePointer || !out || num_nodes < 0 || tile_h <= 0 || tile_w <= 0)
+        return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_tile_stats: bad argument (N=%d, tile %dx%d)", num_nodes, tile_h, tile_w);
+    if (nodePointer[0] < 0) return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_tile_stats: nodePointer[0] = %d is negative", nodePointer[0]);
+    for (int32_t r = 0; r < num_nodes; ++r)
+        if (nodePointer[r + 1] < nodePointer[r])
+            return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_tile_stats: nodePointer decreases at row %d", r);
+    const int64_t E = nodePointer[num_nodes];
+    if (E > 0 && !edgeList) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_tile_stats: null edge list");
+    const int64_t windows = ((int64_t)num_nodes + tile_h - 1) / tile_h;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = num_threads > 0 ? num_threads : (hw ? (int)hw : 1);
+    if ((int64_t)nthreads > windows) nthreads = (int)std::max<int64_t>(1, windows);
+    if (E < (1 << 15)) nthreads = 1;
+    std::atomic<int64_t> next{0};
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(64, windows / (nthreads * 8) + 1));
+    struct Acc { int64_t sliding = 0, condensed = 0, uniq = 0, nonempty = 0, max_sliding = 0, max_condensed = 0; };
+    std::vector<Acc> accs((size_t)nthreads);
+    auto worker = [&](int tid) {
+        WindowScratch s;
+        Acc a;
+        for (;;) {
+            const int64_t w0 = next.fetch_add(chunk);
+            if (w0 >= windows) break;
+            const int64_t w1 = std::min(windows, w0 + chunk);
+            for (int64_t w = w0; w < w1; ++w) {
+                const int64_t n0 = w * tile_h, n1 = std::min<int64_t>(n0 + tile_h, num_nodes);
+                bool rows_sorted;
+                const uint32_t uniq = window_unique(edgeList, nodePointer, n0, n1, s, &rows_sorted);
+                if (!uniq) continue;
+                const uint32_t* U = s.a.data();
+                int64_t slide = 0;
+                for (uint32_t i = 0; i < uniq; ++slide) {
+                    const uint64_t end = (uint64_t)U[i] + (uint64_t)tile_w;
+                    while (i < uniq && U[i] < end) ++i;
+                }
+                const int64_t cond = ((int64_t)uniq + tile_w - 1) / tile_w;
+                a.sliding += slide; a.condensed += cond; a.uniq += uniq; a.nonempty += 1;
+                a.max_sliding = std::max(a.max_sliding, slide); a.max_condensed = std::max(a.max_condensed, cond);
+            }
+        }
+        accs[(size_t)tid] = a;
+    };
+    if (nthreads <= 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker, t);
+        for (auto& t : pool) t.join();
+    }
+    Acc a;
+    for (const Acc& b : accs) {
+        a.sliding += b.sliding; a.condensed += b.condensed; a.uniq += b.uniq; a.nonempty += b.nonempty;
+        a.max_sliding = std::max(a.max_sliding, b.max_sliding); a.max_condensed = std::max(a.max_condensed, b.max_condensed);
+    }
+    out->windows = windows; out->nonempty_windows = a.nonempty; out->edges = E; out->unique_columns = a.uniq;
+    out->sliding_tiles = a.sliding; out->condensed_tiles = a.condensed;
+    out->max_sliding_per_window = a.max_sliding; out->max_condensed_per_window = a.max_condensed;
+    return TCGNN_OK;
+}
+
 } // extern "C"

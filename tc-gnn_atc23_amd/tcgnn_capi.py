@@ -28,6 +28,12 @@ class PlanInfo(ctypes.Structure):
                 ("column_buckets", _i32), ("reserved", _i32)]
 
 
+class TileStats(ctypes.Structure):
+    _fields_ = [("windows", _i64), ("nonempty_windows", _i64), ("edges", _i64), ("unique_columns", _i64),
+                ("sliding_tiles", _i64), ("condensed_tiles", _i64), ("max_sliding_per_window", _i64),
+                ("max_condensed_per_window", _i64)]
+
+
 # every symbol include/tcgnn.h declares, with its signature
 SIGNATURES = {
     "tcgnn_abi_version": (ctypes.c_int, []),
@@ -35,6 +41,7 @@ SIGNATURES = {
     "tcgnn_last_error": (ctypes.c_char_p, []),
     "tcgnn_preprocess": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _i32]),
     "tcgnn_preprocess_gpu": (ctypes.c_int, [_i32p, _i32p, _i32, _i64, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _vp]),
+    "tcgnn_tile_stats": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, ctypes.POINTER(TileStats), _i32]),
     "tcgnn_plan_create": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_create_sharded": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i32, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_destroy": (ctypes.c_int, [_vp]),

@@ -122,3 +122,27 @@ def synthetic_shape(name, seed=0, device="cpu", scale=1.0):
     nnz2 = min(nnz2, n2 * (n2 - 1) // 2)
     rp, col = synthetic_csr(n2, nnz2, seed=seed, device=device)
     return rp, col, dim, classes
+
+
+def tile_statistics(row_pointers, column_index, tile_h=16, tile_w=8, threads=0):
+    """Sliding-window vs condensed tile counts of a CSR graph - the numbers 3_cnt_TC_blk_SpMM.py:38-94
+    (16x8) and 3_cnt_TC_blk_SDDMM.py (16x16) print as `dataset,origin,reduced,reduction (%)`, plus the
+    tile fill ("eff" of logs/16x8_reduction.csv) and blocks per window.  Host tensors / arrays; runs in
+    the threaded host library (tcgnn_tile_stats), no Python loop over windows."""
+    import tcgnn_capi as C
+    rp = np.ascontiguousarray(torch.as_tensor(row_pointers).cpu().numpy(), dtype=np.int32)
+    ci = np.ascontiguousarray(torch.as_tensor(column_index).cpu().numpy(), dtype=np.int32)
+    if rp.ndim != 1 or rp.size < 1:
+        raise ValueError("row_pointers must hold N + 1 entries")
+    if ci.size < int(rp[-1]):
+        raise ValueError("column_index is shorter than row_pointers[-1]")
+    st = C.TileStats()
+    C.check(C.lib.tcgnn_tile_stats(ci.ctypes.data, rp.ctypes.data, rp.size - 1, tile_h, tile_w, st, threads), "tcgnn_tile_stats")
+    out = {f: int(getattr(st, f)) for f, _ in C.TileStats._fields_}
+    area = float(tile_h * tile_w)
+    out["reduction_pct"] = 100.0 * (out["sliding_tiles"] - out["condensed_tiles"]) / out["sliding_tiles"] if out["sliding_tiles"] else 0.0
+    out["sliding_fill"] = out["edges"] / (out["sliding_tiles"] * area) if out["sliding_tiles"] else 0.0
+    out["condensed_fill"] = out["edges"] / (out["condensed_tiles"] * area) if out["condensed_tiles"] else 0.0
+    out["sliding_per_window"] = out["sliding_tiles"] / out["windows"] if out["windows"] else 0.0
+    out["condensed_per_window"] = out["condensed_tiles"] / out["windows"] if out["windows"] else 0.0
+    return out

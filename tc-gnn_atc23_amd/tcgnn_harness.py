@@ -73,6 +73,14 @@ def load_graph(args):
     return G.TCGNN_dataset(path, args.dim, args.classes, load_from_txt=False, seed=args.seed)
 
 
+def node_nll_loss(log_probs, y):
+    """F.nll_loss(log_probs, y) of main_tcgnn.py:149 (mean over all nodes, no class weights, no ignore_index hit)
+    as a gather + mean: torch's 2-D nll_loss kernels reduce N = 233k rows in ONE workgroup (0.36 ms forward +
+    0.23 ms backward per Reddit epoch, 8 % of the GCN epoch, measured with rocprofv3); this form is 30x faster
+    and differs only in summation order."""
+    return -log_probs.gather(1, y.view(-1, 1)).mean()
+
+
 def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9):
     """The timed part of main_tcgnn.py (:141-181) on tensors that already live on the GPU:
     Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones."""
@@ -85,7 +93,7 @@ def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, e
     def train():
         model.train()
         optimizer.zero_grad()
-        loss = F.nll_loss(model(x, meta), y)
+        loss = node_nll_loss(model(x, meta), y)
         loss.backward()
         optimizer.step()
         return loss

@@ -51,7 +51,7 @@ class TCGNNFunction_SAG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_output):
-        d_input = backend().forward(d_output.contiguous(), *ctx.meta)[0]
+        d_input = backend().forward(d_output.contiguous(), *ctx.meta)[0] if ctx.needs_input_grad[0] else None
         return (d_input,) + (None,) * 5
 
 
@@ -68,7 +68,9 @@ class TCGNNFunction(torch.autograd.Function):
     def backward(ctx, d_output):
         X, weights = ctx.saved_tensors
         g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
-        return (torch.mm(g, weights.t()), torch.mm(X.t(), g)) + (None,) * 5
+        # the input features of the first layer need no gradient: skip their N x in_dim product
+        d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
+        return (d_input, torch.mm(X.t(), g)) + (None,) * 5
 
 
 class TCGNNFunction_GIN(torch.autograd.Function):
@@ -84,9 +86,10 @@ class TCGNNFunction_GIN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_output):
         agg, weights = ctx.saved_tensors
-        d_agg = torch.mm(d_output, weights.t())
         d_weights = torch.mm(agg.t(), d_output)
-        d_input = backend().forward(d_agg.contiguous(), *ctx.meta)[0]
+        d_input = None
+        if ctx.needs_input_grad[0]:
+            d_input = backend().forward(torch.mm(d_output, weights.t()).contiguous(), *ctx.meta)[0]
         return (d_input, d_weights) + (None,) * 5
 
 
@@ -112,7 +115,7 @@ class TCGNNFunction_AGNN(torch.autograd.Function):
         row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow = ctx.meta
         d_output = d_output.contiguous()
         g = backend().forward_AGNN(d_output, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
-        d_input = torch.mm(g, weights.t())
+        d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
         d_weights = torch.mm(X.t(), g)
         d_att = backend().forward_ef(d_output, *ctx.meta)[0]
         # reference: mm(d_att[None, :].expand(n_heads, -1), column_index[:, None].float()).T, i.e. the

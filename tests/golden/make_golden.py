@@ -165,6 +165,50 @@ def make_dataset():
         torch.Tensor.cuda = saved
 
 
+def make_tile_stats():
+    """Runs find_dense() of 3_cnt_TC_blk_SpMM.py (16x8) and 3_cnt_TC_blk_SDDMM.py (16x16) on seeded graphs.
+    The scripts execute their dataset loop at import, so only the function definition is compiled (from the
+    reference checkout, at generation time) into a namespace that carries the script's tile constants."""
+    import ast, contextlib, io
+    out = {}
+    graphs = {}
+    rng = np.random.default_rng(9)
+    for name, n, m in (("a", 50, 300), ("b", 200, 4000), ("c", 333, 900)):
+        src = rng.integers(0, n, size=m); dst = rng.integers(0, n, size=m)
+        if name == "c":   # clustered ids: sliding tiles cover several neighbours
+            src = (src // 7) * 7 + rng.integers(0, 3, size=m); src = np.minimum(src, n - 1)
+        key = np.unique(dst.astype(np.int64) * n + src)       # the scripts exit on duplicate edges
+        graphs[name] = (key % n, key // n, n)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        for script, tag in (("3_cnt_TC_blk_SpMM.py", "16x8"), ("3_cnt_TC_blk_SDDMM.py", "16x16")):
+            tree = ast.parse(open(os.path.join(REF, script)).read())
+            ns = {"np": np, "defaultdict": __import__("collections").defaultdict, "sys": sys}
+            for node in tree.body:
+                if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "").startswith("dense_tile_"):
+                    exec(compile(ast.Module([node], []), script, "exec"), ns)
+                if isinstance(node, ast.FunctionDef) and node.name == "find_dense":
+                    exec(compile(ast.Module([node], []), script, "exec"), ns)
+            for name, (src, dst, n) in graphs.items():
+                path = os.path.join(tmp, name)
+                np.savez(path + ".npz", src_li=src, dst_li=dst, num_nodes=n)
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    ns["find_dense"](path, name)
+                _, origin, reduced, pct = buf.getvalue().strip().split(",")
+                out["%s_%s" % (name, tag)] = np.array([int(origin), int(reduced)])
+                out["%s_%s_pct" % (name, tag)] = pct
+                out["%s_tile" % tag] = np.array([ns["dense_tile_H"], ns["dense_tile_W"]])
+    finally:
+        os.chdir(cwd)
+    for name, (src, dst, n) in graphs.items():
+        out[name + "_src"] = src.astype(np.int32); out[name + "_dst"] = dst.astype(np.int32); out[name + "_n"] = n
+    np.savez_compressed(os.path.join(HERE, "tile_stats.npz"), **out)
+    print("tile_stats:", {k: v.tolist() for k, v in out.items() if k.endswith("x8") or k.endswith("x16")})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not found at %s - fixtures can only be generated in the build container" % REF)
@@ -174,3 +218,4 @@ if __name__ == "__main__":
     make_sgt(ref)
     make_layers(ref)
     make_dataset()
+    make_tile_stats()

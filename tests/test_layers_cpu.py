@@ -106,3 +106,37 @@ def test_synthetic_generator_is_seeded_symmetric_and_canonical():
     assert (a != a.T).nnz == 0 and a.diagonal().sum() == 0 and a.has_canonical_format
     rp3, col3, dim, classes = G.synthetic_shape("reddit", scale=0.01)
     assert (dim, classes) == (602, 41) and rp3.numel() - 1 == 2329
+
+
+def test_input_gradient_is_skipped_when_not_needed_and_weights_are_unchanged(layers):
+    """First-layer features carry no gradient: the Functions must not compute dX, and dW must not change."""
+    f = np.load(os.path.join(GOLD, "layers_n200.npz"))
+    t = lambda k: torch.from_numpy(f[k])
+    meta = (t("rowptr"), t("col"), t("bp"), t("e2c"), t("e2r"))
+    calls = []
+    inner = layers.backend()
+    spy = types.SimpleNamespace(forward=lambda *a: (calls.append("spmm"), inner.forward(*a))[1],
+                                forward_ef=lambda *a: (calls.append("sddmm"), inner.forward_ef(*a))[1],
+                                forward_AGNN=lambda *a: (calls.append("spmm_val"), inner.forward_AGNN(*a))[1])
+    layers.set_backend(spy)
+    for fn, key, n_bwd in ((layers.TCGNNFunction, "gcn_dW", 1), (layers.TCGNNFunction_GIN, "gin_dW", 0)):
+        x, w = t("X").clone(), t("W").clone().requires_grad_(True)
+        y = fn.apply(x, w, *meta)
+        calls.clear()
+        y.backward(t("dY"))
+        assert x.grad is None and _close(w.grad, f[key]) and calls.count("spmm") == n_bwd
+    x, w, a = t("X").clone(), t("W").clone().requires_grad_(True), t("attention_w").clone().requires_grad_(True)
+    layers.TCGNNFunction_AGNN.apply(x, w, a, *meta).backward(t("dY"))
+    assert x.grad is None and _close(w.grad, f["agnn_dW"]) and _close(a.grad, f["agnn_dattention_w"], tol=1e-4)
+
+
+def test_harness_loss_is_nll_loss():
+    import tcgnn_harness as H
+    torch.manual_seed(0)
+    z = torch.randn(37, 5, requires_grad=True)
+    y = torch.randint(0, 5, (37,))
+    a = H.node_nll_loss(torch.log_softmax(z, 1), y)
+    ga, = torch.autograd.grad(a, z)
+    b = torch.nn.functional.nll_loss(torch.log_softmax(z, 1), y)
+    gb, = torch.autograd.grad(b, z)
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-7) and torch.allclose(ga, gb, rtol=1e-6, atol=1e-8)
