@@ -140,3 +140,15 @@ def test_harness_loss_is_nll_loss():
     b = torch.nn.functional.nll_loss(torch.log_softmax(z, 1), y)
     gb, = torch.autograd.grad(b, z)
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-7) and torch.allclose(ga, gb, rtol=1e-6, atol=1e-8)
+
+
+def test_split_weight_gradient_product_equals_plain_mm():
+    import tcgnn_layers as L
+    torch.manual_seed(1)
+    for n in (100, L._SPLIT_ROWS + 37):
+        A, B = torch.randn(n, 19), torch.randn(n, 7)
+        ref = torch.mm(A.double().t(), B.double())
+        out = L.tall_tn_mm(A, B)
+        assert out.shape == (19, 7) and torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * float(ref.abs().max()))
+    A = torch.randn(L._SPLIT_ROWS + 5, 24)[:, ::2]          # non-contiguous operand
+    assert torch.allclose(L.tall_tn_mm(A, A), torch.mm(A.t(), A), rtol=1e-4, atol=1e-2)
