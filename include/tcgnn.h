@@ -50,7 +50,8 @@ typedef enum tcgnn_status {
     TCGNN_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed             */
     TCGNN_ERR_OOM = 3,         /* host or device allocation failed                       */
     TCGNN_ERR_BAD_GRAPH = 4,   /* metadata inconsistent with the CSR (out-of-range ids)  */
-    TCGNN_ERR_WORKSPACE = 5    /* workspace pointer null or smaller than required        */
+    TCGNN_ERR_WORKSPACE = 5,   /* workspace pointer null or smaller than required        */
+    TCGNN_ERR_UNSUPPORTED = 6  /* the fused entry point does not cover this plan / width  */
 } tcgnn_status;
 
 /* Opaque device-resident translation of one graph: the condensed 16x32 tile stream the kernels
@@ -176,6 +177,33 @@ int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge
  * TCGNN.backward_ef (TCGNN.cpp:126-150).  d_ef: fp32 [E], fully overwritten. */
 int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D,
                 void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused AGNN layer products (one gather of the neighbour rows feeds both) ----------------
+ *
+ * The reference's AGNN layer (gnn_conv.py:115-158) calls forward_ef and forward_AGNN back to back on
+ * the same matrix, and again in backward; each call gathers every neighbour row once.  These two
+ * entry points compute the same results with ONE pass over the tile stream.
+ *
+ * forward:   ef[e] = <X[row e], X[col e]>                         (= tcgnn_sddmm)
+ *            Y     = A_att * X,  att[e] = fl32(w * ef[e])          (= tcgnn_spmm_val on w * ef)
+ *            *d_ef_absmax = bit pattern of max |ef| (device word, consumed by the backward call)
+ * backward:  G     = A_att * dY, att[e] = fl32(w * ef[e]) with the saved ef   (gnn_conv.py:143)
+ *            *d_dw = sum_e <dY[row e], dY[col e]> * (float)col(e)             (gnn_conv.py:150-153:
+ *                    the reference's d_attention_w, mm(backward_ef(dY)[None,:], column_index[:,None].float()))
+ * d_w is the attention weight as a DEVICE scalar (no host read-back).  Rounding is the same as in
+ * the separate calls (10-bit mantissa operands, fp32 accumulate); the power-of-two scale of att comes
+ * from a bound instead of a pass over E, so results equal the separate calls bit for bit unless an
+ * edge weight is more than 2^-20 below that bound.  d_dw is a fixed-order reduction (deterministic).
+ * Supported for canonical plans (sorted, duplicate-free rows), D <= 128, E >= 4:
+ * tcgnn_agnn_supported() tells; otherwise the calls return TCGNN_ERR_UNSUPPORTED and the caller
+ * uses the three separate entry points. */
+int tcgnn_agnn_supported(const tcgnn_plan* plan, int32_t D);
+int tcgnn_agnn_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef,
+                       uint32_t* d_ef_absmax, float* d_Y, int32_t D, void* d_workspace,
+                       size_t workspace_bytes, void* stream);
+int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef,
+                        const uint32_t* d_ef_absmax, float* d_G, float* d_dw, int32_t D,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ import torch
 import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
-           "plan_info", "kernel_timing", "clear_plan_cache"]
+           "plan_info", "kernel_timing", "clear_plan_cache", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward"]
 
 _PLAN_CACHE_SIZE = 8
 _plans = collections.OrderedDict()  # key -> (handle, tensors kept alive)
@@ -275,6 +275,66 @@ def forward_ef(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeT
         st = _c.lib.tcgnn_sddmm(plan, input.data_ptr(), out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
     _c.check(st, "tcgnn_sddmm")
     return [out]
+
+
+# ---- additions (not in the reference module): the two products of an AGNN layer in one pass ------------
+
+def agnn_fused_supported(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """True if agnn_fused_forward / agnn_fused_backward cover this graph and width (canonical CSR, D <= 128, E >= 4)."""
+    if not (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32) or input.shape[0] == 0 or input.shape[1] == 0:
+        return False
+    with torch.cuda.device(input.device):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    return bool(_c.lib.tcgnn_agnn_supported(plan, input.shape[1]))
+
+
+def _weight_scalar(attention_w, dev):
+    _check_input(attention_w, "attention_w")
+    _check_float(attention_w, "attention_w")
+    if attention_w.numel() != 1 or attention_w.device != dev:
+        raise RuntimeError("attention_w must hold one value (n_heads = 1) on the input's device")
+
+
+def agnn_fused_forward(input, nodePointer, edgeList, attention_w, blockPartition, edgeToColumn, edgeToRow):
+    """[Y, ef, ef_absmax] with ef = forward_ef(input), Y = forward_AGNN(input, attention_w * ef): what
+    gnn_conv.py:125-132 computes with two calls (two gathers of the neighbour rows), here in one pass.
+    ef_absmax (one int32 word on the device) must be handed to agnn_fused_backward."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    dev = input.device
+    _weight_scalar(attention_w, dev)
+    N, D = input.shape
+    out = torch.empty_like(input)
+    ef = torch.empty(edgeList.numel(), dtype=torch.float32, device=dev)
+    absmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_agnn_forward(plan, input.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), absmax.data_ptr(),
+                                       out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_agnn_forward")
+    return [out, ef, absmax]
+
+
+def agnn_fused_backward(d_output, nodePointer, edgeList, attention_w, ef, ef_absmax, blockPartition, edgeToColumn, edgeToRow):
+    """[G, d_w] with G = forward_AGNN(d_output, attention_w * ef) and d_w = <forward_ef(d_output), edgeList.float()>
+    (gnn_conv.py:143 and :150-153), one pass."""
+    _six(d_output, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    dev = d_output.device
+    _weight_scalar(attention_w, dev)
+    _check_input(ef, "ef")
+    _check_float(ef, "ef")
+    if ef.numel() != edgeList.numel() or ef_absmax.numel() != 1 or ef_absmax.dtype != torch.int32 or not ef_absmax.is_cuda:
+        raise RuntimeError("ef / ef_absmax are not what agnn_fused_forward returned for this graph")
+    N, D = d_output.shape
+    out = torch.empty_like(d_output)
+    d_w = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_agnn_backward(plan, d_output.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), ef_absmax.data_ptr(),
+                                        out.data_ptr(), d_w.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_agnn_backward")
+    return [out, d_w]
 
 
 backward = forward        # TCGNN.cpp:270

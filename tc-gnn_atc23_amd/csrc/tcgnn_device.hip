@@ -973,6 +973,319 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused AGNN products: one gather of a tile's 32 neighbour rows feeds BOTH the edge scores
+// (SDDMM) and the edge-weighted aggregation (SpMM), which the AGNN layer always wants together.
+//
+// Per tile:   S^T = Xc * Xw^T   (MFMA #1: tile columns as rows m, the 16 window rows as columns n, K = D)
+//             lane (g, i) then holds, for window row i, the scores of tile columns 4g..4g+3 and
+//             16+4g..16+4g+3 - exactly an A fragment of MFMA #2 if its eight k slots are NAMED that
+//             way, so no data moves between lanes:
+//             Y  += att * Xc    (MFMA #2: k slot j <-> tile column (j < 4 ? 4g + j : 16 + 4g + j - 4))
+// The gathered rows land lane-linear in LDS (lane (g, i) DMAs halves 32ks + 8g.. of tile column
+// 16sub + i to slot lane*16 of block (sub, ks)); MFMA #1 reads each lane's own slot back, MFMA #2
+// reads the same bytes through ds_read_b64_tr_b16 with the k-slot naming above.  One buffer is
+// enough: every LDS read of tile t completes before the gather of tile t+1 is issued, and that
+// gather is in flight while tile t is multiplied.
+//   forward  (BWD = false): ef = scores (staged per row, flushed as contiguous runs, as in
+//            sddmm_kernel), att = fl32(w * ef), max |ef| recorded for the backward call's scale.
+//   backward (BWD = true):  att = fl32(w * ef_saved) (edge values DMA'd one tile ahead),
+//            scores of dY are only reduced against the column ids: sum_e s[e] * (float)col(e).
+// ------------------------------------------------------------------------------------------
+struct AgnnArgs {
+    const int64_t* wb_ptr;
+    const int32_t* order;
+    const int32_t* cols;
+    const uint32_t* mask;
+    const int32_t* ebase;
+    const _Float16* x16;
+    const uint32_t* hdr;
+    const float* w;            // attention weight, device scalar
+    float* ef;                 // forward: out [E]; backward: the saved scores (read only)
+    uint32_t* ef_absmax;       // bit pattern of max |ef|: forward accumulates, backward reads
+    float* y;                  // [N, D]
+    double* partial;           // backward: one slot per workgroup
+    int32_t N, Nc, row_off, Dpad, D, stride;
+    int64_t E;
+    const int32_t* rowptr;
+};
+
+static constexpr int agnn_wave_lds(int ks, bool bwd) {
+    return 2 * ks * 1024 + kPadBytes + (bwd ? 2048 : 16 * kSddmmStageCap * 4 + 256);
+}
+
+template <int NT, int WAVES, bool BWD>
+__global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = (NT + 1) / 2;
+    constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
+    constexpr int CAP = kSddmmStageCap;
+    constexpr int NQ = 2 * KS + (BWD ? 2 : 0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int w = a.order[blockIdx.x];
+    const int64_t tb = a.wb_ptr[w], te_w = a.wb_ptr[w + 1];
+    const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
+    int64_t t = tb + wave * chunk;
+    const int64_t te = t + chunk < te_w ? t + chunk : te_w;
+    const int64_t stride = a.stride;
+    const int kx = scale_exp_from_bits(a.hdr[0]);
+    const bool two_step = kx > 63 || kx < -63;                     // score = acc * 2^(-2kx), in two factors if needed
+    const float inv_a = two_step ? pow2f(-kx) : pow2f(-2 * kx), inv_b = two_step ? pow2f(-kx) : 1.0f;
+    const float wv = a.w[0];
+    // power-of-two scale of the edge weights att = w * ef.  forward: |ef| <= Dpad * max|x|^2 (no pass over E);
+    // backward: the recorded max |ef|.  Rounding to a 10-bit mantissa does not depend on the scale.
+    float att_bound;
+    if constexpr (BWD) att_bound = fabsf(wv) * __uint_as_float(a.ef_absmax[0]);
+    else { const float xm = __uint_as_float(a.hdr[0]); att_bound = fabsf(wv) * (float)a.Dpad * xm * xm; }
+    const int ka = scale_exp_from_bits(__float_as_uint(att_bound));
+    const float sa = pow2f(ka);
+    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
+    const MetaSource meta(a.cols, a.mask, a.ebase, lane);
+    const uint32_t ring = (uint32_t)(uintptr_t)((LDS_AS char*)(smem + wave * WAVE_LDS));
+    const uint32_t pad = ring + 2 * KS * 1024;
+    const uint32_t aux = pad + kPadBytes;                          // forward: output staging; backward: edge-value pad
+    uint32_t boff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) boff[ks] = (ks * 32 + 8 * g < a.Dpad) ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u;
+    // pad: cols[32] | mask[16] | ebase[16]; this lane: ids of tile columns i and 16+i (for the gather), mask and edge offset of ROW i
+    const uint32_t idaddr[4] = {pad + (uint32_t)i * 4u, pad + 64u + (uint32_t)i * 4u, pad + 128u + (uint32_t)i * 4u, pad + 192u + (uint32_t)i * 4u};
+    uint32_t qaddr[NQ];
+#pragma unroll
+    for (int k = 0; k < 2 * KS; ++k) qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    if constexpr (BWD) { qaddr[2 * KS] = aux + (uint32_t)lane * 16u; qaddr[2 * KS + 1] = aux + 1024u + (uint32_t)lane * 16u; }
+    const uint32_t caddr[2] = {pad + 16u * (uint32_t)g, pad + 64u + 16u * (uint32_t)g};   // ids of my eight tile columns (backward)
+    // transpose reads: this lane addresses k row j = i >> 2 (tile column 4g + j of half h), feature quad q = i & 3 of slice s
+    uint32_t raddr[NT][2];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            raddr[s][h] = ring + (uint32_t)((h * KS + (s >> 1)) * 1024 + ((2 * (s & 1) + ((i & 3) >> 1)) * 16 + 4 * g + (i >> 2)) * 16 + 8 * (i & 1));
+    const uint32_t stg_i = aux + (uint32_t)i * CAP * 4u;
+    const uint32_t junk = aux + 16u * CAP * 4u + (uint32_t)lane * 4u;
+    const uint32_t flush_base = aux + (uint32_t)lane * 4u;
+    const uint32_t lowq[2] = {(1u << (4 * g)) - 1u, (1u << (16 + 4 * g)) - 1u};         // condensed columns left of my two quads
+
+    floatx4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+    uint32_t emax = 0u;
+    float dsum = 0.f;
+
+    if (t < te) {
+        // B operand of MFMA #1: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
+        int64_t arow = (int64_t)w * kWinRows + i;
+        arow = arow < a.N ? arow + a.row_off : a.Nc;
+        const _Float16* ap = a.x16 + arow * stride + 8 * g;
+        half8 af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
+        const int64_t wrow = (int64_t)w * kWinRows;
+        const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
+        char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
+        uint32_t cnt = 0u, rstart = ~0u;                           // staged results of row i / window-relative position of the first
+
+        auto flush = [&]() {
+            uint32_t vals[16];
+            lds_rows_block8<CAP * 4, 0>(flush_base, vals);
+            lds_rows_block8<CAP * 4, 8>(flush_base, vals + 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
+                const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
+                if ((uint32_t)lane < c_r) *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+            }
+            cnt = 0u; rstart = ~0u;
+        };
+        auto dma_b = [&](const uint32_t* cid) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + (sub * KS + ks) * 1024), 16,
+                                                                (int)cid[sub], (int)boff[ks], 0, 0, 0);
+        };
+        struct Cur { uint32_t m, eb; int sh[2]; uintx4 c[2]; };
+        // saved scores of row i inside my two column quads: 4 consecutive floats each, clamped to stay inside ef
+        auto dma_vals = [&](Cur& c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & lowq[h]);
+                int64_t lo = e0 < a.E - 4 ? e0 : a.E - 4;
+                c.sh[h] = (int)(e0 - lo);
+                __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)(aux + h * 1024), 16, 0, 0);
+            }
+        };
+        auto stage = [&](Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
+            wait_vm0();
+            uint32_t v[4];
+            uintx4 q[NQ];
+            lds_ids_block<4>(idaddr, v, qaddr[0], q[0]);          // next tile: two row ids, my row's mask and edge offset; + operand 0
+            lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands [+ my saved scores]
+            Cur nx;
+            nx.m = v[2]; nx.eb = v[3]; nx.sh[0] = nx.sh[1] = 0;
+            if constexpr (BWD) lds_q_block<2, 0>(caddr, nx.c);
+            half4 lo[NT], hi[NT];
+            lds_tr_block<NT, 0>(raddr, lo, hi);
+            const bool more = tn < te;
+            const int64_t tnn = tn + 1;
+            if (more) {
+                dma_b(v);
+                if constexpr (BWD) dma_vals(nx);
+                if (tnn < te) meta.dma(tnn, pad);
+            }
+            // ---- tile tcur: scores
+            floatx4 S[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                S[sub] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (__any(((cur.m >> (16 * sub)) & 0xffffu) != 0u)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        S[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, q[sub * KS + ks]), af[ks], S[sub], 0, 0, 0);
+                }
+            }
+            // ---- edge weights of row i for my eight tile columns
+            half8 a16;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint32_t nib = (cur.m >> (16 * sub + 4 * g)) & 0xfu;
+                const uint32_t base = (uint32_t)__popc(cur.m & lowq[sub]);
+                floatx4 sv;
+                if constexpr (BWD) sv = __builtin_bit_cast(floatx4, q[2 * KS + sub]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = (nib >> r) & 1u;
+                    const uint32_t k = (uint32_t)__popc(nib & ((1u << r) - 1u));
+                    float sc = S[sub][r] * inv_a;
+                    if (two_step) sc *= inv_b;
+                    float att;
+                    if constexpr (BWD) {
+                        const uint32_t kk = k + (uint32_t)cur.sh[sub];
+                        const float v01 = (kk & 1u) ? sv[1] : sv[0];
+                        const float v23 = (kk & 1u) ? sv[3] : sv[2];
+                        att = ((kk & 2u) ? v23 : v01) * wv;
+                        dsum += on ? sc * (float)(int32_t)cur.c[sub][r] : 0.0f;
+                    } else {
+                        lds_write_b32(on ? stg_i + ((cnt + base + k) << 2) : junk, sc);
+                        att = sc * wv;
+                        const uint32_t ab = __float_as_uint(sc) & 0x7fffffffu;
+                        emax = (on && ab > emax) ? ab : emax;
+                    }
+                    a16[4 * sub + r] = on ? to_half_rna(att * sa) : (_Float16)0.0f;
+                }
+            }
+            // ---- aggregation
+#pragma unroll
+            for (int s = 0; s < NT; ++s) {
+                const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16, bf, acc[s], 0, 0, 0);
+            }
+            if constexpr (!BWD) {
+                if (rstart == ~0u && cur.m != 0u) rstart = cur.eb - (uint32_t)e_w0;
+                cnt += (uint32_t)__popc(cur.m);
+                // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
+                if (!more || __any(cnt > (uint32_t)(CAP - 32))) flush();
+            }
+            cur = nx;
+            tcur = tn;
+            tn = tnn;
+            return more;
+        };
+
+        // prologue: metadata of the first tile, its operands [and saved scores], metadata of the second
+        meta.dma(t, pad);
+        wait_vm0();
+        Cur cur;
+        {
+            uint32_t v[4];
+            uintx4 dummy;
+            lds_ids_block<4>(idaddr, v, qaddr[0], dummy);
+            cur.m = v[2]; cur.eb = v[3]; cur.sh[0] = cur.sh[1] = 0;
+            if constexpr (BWD) lds_q_block<2, 0>(caddr, cur.c);
+            dma_b(v);
+            if constexpr (BWD) dma_vals(cur);
+        }
+        int64_t tn = t + 1;
+        if (tn < te) meta.dma(tn, pad);
+        while (stage(cur, t, tn)) {}
+        wait_vm0();
+    }
+
+    if constexpr (BWD) {
+        // sum_e score(e) * col(e): per-wavefront double, then one slot per workgroup (fixed order -> deterministic)
+        double d = (double)dsum;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+        __syncthreads();
+        double* dred = reinterpret_cast<double*>(smem);
+        if (lane == 0) dred[wave] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int ww = 0; ww < WAVES; ++ww) tot += dred[ww];
+            a.partial[blockIdx.x] = tot;
+        }
+    } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)emax, off, 64); emax = o > emax ? o : emax; }
+        if (lane == 0 && emax != 0u) atomicMax(a.ef_absmax, emax);
+    }
+
+    // ---- combine the wavefronts' partial sums in a fixed order and store
+    const float inv1 = pow2f(-kx), inv2 = pow2f(-ka);
+    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
+    if constexpr (WAVES > 1) {
+        __syncthreads(); // every wave is done with its LDS
+        floatx4* red = reinterpret_cast<floatx4*>(smem);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
+        __syncthreads();
+        for (int s = wave; s < NT; s += WAVES) {
+            floatx4 v = red[s * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) {
+                const floatx4 o = red[(ww * NT + s) * 64 + lane];
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            const int colg = 16 * s + i;
+            if (colg < a.D) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int colg = 16 * s + i;
+            if (colg < a.D) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii] * inv1 * inv2;
+            }
+        }
+    }
+}
+
+// partial[0..n) -> out[0], fixed order
+__global__ void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) s += partial[k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+
+// ------------------------------------------------------------------------------------------
 // fallbacks for non-canonical CSR rows (unsorted or duplicated column ids)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __restrict__ rowptr,
@@ -1074,6 +1387,20 @@ static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwg, hipStr
     return hipGetLastError();
 }
 
+template <int WAVES, bool BWD>
+static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t stream) {
+    const dim3 grid((unsigned)nwg), block(WAVES * 64);
+    const size_t lds = (size_t)WAVES * agnn_wave_lds((nt + 1) / 2, BWD);
+#define TCGNN_AGNN_CASE(n) case n: hipLaunchKernelGGL((agnn_kernel<n, WAVES, BWD>), grid, block, lds, stream, args); break;
+    switch (nt) {
+        TCGNN_AGNN_CASE(1) TCGNN_AGNN_CASE(2) TCGNN_AGNN_CASE(3) TCGNN_AGNN_CASE(4)
+        TCGNN_AGNN_CASE(5) TCGNN_AGNN_CASE(6) TCGNN_AGNN_CASE(7) TCGNN_AGNN_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TCGNN_AGNN_CASE
+    return hipGetLastError();
+}
+
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
@@ -1096,6 +1423,8 @@ static size_t workspace_bytes_for(int32_t N, int32_t D) {
     const size_t body = ((size_t)N + 1) * dpad * sizeof(_Float16);
     return kHdrBytes + ((body + 255) / 256) * 256;
 }
+// the fused AGNN backward keeps one double per workgroup (= per window) behind the fp16 image
+static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std::max(plan->nw_eff, 1) * sizeof(double)) + 255) / 256 * 256; }
 
 // enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
@@ -1176,10 +1505,67 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     return TCGNN_OK;
 }
 
+static bool agnn_supported(const tcgnn_plan* plan, int32_t D) {
+    return plan && plan->canonical && D >= 1 && D <= kMaxChunkDims && plan->E >= 4;
+}
+
+static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_absmax, float* d_Y,
+                    float* d_dw, int32_t D, void* ws, size_t ws_bytes, void* stream_v, bool bwd) {
+    const char* name = bwd ? "tcgnn_agnn_backward" : "tcgnn_agnn_forward";
+    if (!plan || D < 1 || !d_w || !d_absmax || (bwd && !d_dw) || (plan->N > 0 && (!d_X || !d_Y)) || (plan->E > 0 && !d_ef))
+        return fail(TCGNN_ERR_INVALID_ARG, "%s: null argument or D < 1", name);
+    if (!agnn_supported(plan, D))
+        return fail(TCGNN_ERR_UNSUPPORTED, "%s: needs a canonical plan, D <= %d and E >= 4 (canonical=%d, D=%d, E=%lld)", name,
+                    kMaxChunkDims, plan->canonical, D, (long long)plan->E);
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan);
+    if (!ws || ws_bytes < need) return fail(TCGNN_ERR_WORKSPACE, "%s: workspace needs %zu bytes, got %zu", name, need, ws_bytes);
+    if ((int64_t)plan->nw_eff * kWinRows < plan->N) {   // rows the caller's windows do not cover stay zero
+        HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
+        if (!bwd) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
+    }
+    if (!bwd) HIP_TRY(hipMemsetAsync(d_absmax, 0, sizeof(uint32_t), stream));
+    const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
+    if (rc) return rc;
+    double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D));
+    if (plan->nw_eff == 0) {
+        if (bwd) HIP_TRY(hipMemsetAsync(d_dw, 0, sizeof(float), stream));
+        return TCGNN_OK;
+    }
+    AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
+               plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr};
+    const int nt = dpad / 16;
+    {
+        KernelTimer timer(plan, stream);
+        hipError_t e;
+        if (plan->waves == 4) e = bwd ? launch_agnn<4, true>(nt, a, plan->nw_eff, stream) : launch_agnn<4, false>(nt, a, plan->nw_eff, stream);
+        else                  e = bwd ? launch_agnn<1, true>(nt, a, plan->nw_eff, stream) : launch_agnn<1, false>(nt, a, plan->nw_eff, stream);
+        HIP_TRY(e);
+    }
+    if (bwd) {
+        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, plan->nw_eff, d_dw);
+        HIP_TRY(hipGetLastError());
+    }
+    return TCGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
+
+int tcgnn_agnn_supported(const tcgnn_plan* plan, int32_t D) { return agnn_supported(plan, D) ? 1 : 0; }
+
+int tcgnn_agnn_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_ef_absmax, float* d_Y,
+                       int32_t D, void* ws, size_t ws_bytes, void* stream) {
+    return run_agnn(plan, d_X, d_w, d_ef, d_ef_absmax, d_Y, nullptr, D, ws, ws_bytes, stream, false);
+}
+
+int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef, const uint32_t* d_ef_absmax,
+                        float* d_G, float* d_dw, int32_t D, void* ws, size_t ws_bytes, void* stream) {
+    return run_agnn(plan, d_dY, d_w, const_cast<float*>(d_ef), const_cast<uint32_t*>(d_ef_absmax), d_G, d_dw, D, ws, ws_bytes, stream, true);
+}
 
 int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
@@ -1335,7 +1721,7 @@ int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, in
 
 size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     if (!plan || D < 1) return 0;
-    return workspace_bytes_for(plan->Nc, D);
+    return workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan);   // (the fused AGNN calls' reduction slots ride along)
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {

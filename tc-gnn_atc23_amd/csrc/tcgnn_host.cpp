@@ -109,6 +109,7 @@ const char* tcgnn_status_string(int status) {
         case TCGNN_ERR_OOM: return "out of memory";
         case TCGNN_ERR_BAD_GRAPH: return "graph metadata inconsistent";
         case TCGNN_ERR_WORKSPACE: return "workspace missing or too small";
+        case TCGNN_ERR_UNSUPPORTED: return "not supported by the fused entry point";
         default: return "unknown status";
     }
 }

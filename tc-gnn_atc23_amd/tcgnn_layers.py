@@ -24,6 +24,7 @@ import time
 import torch
 
 n_heads = 1  # gnn_conv.py:10
+USE_FUSED_AGNN = True  # tests switch it off to compare with the separate calls
 
 _backend = None
 
@@ -114,34 +115,52 @@ class TCGNNFunction_GIN(torch.autograd.Function):
 
 
 class TCGNNFunction_AGNN(torch.autograd.Function):
-    """AGNN layer: edge scores by SDDMM, then edge-weighted aggregation."""
+    """AGNN layer: edge scores by SDDMM, then edge-weighted aggregation.
+
+    When the backend offers the fused products (TCGNN.agnn_fused_*: one gather of the neighbour rows
+    for both, no [E]-sized attention / gradient tensors) they are used; the values are those of the
+    separate calls below, which remain the path for anything the fused kernels do not cover."""
 
     @staticmethod
     def forward(ctx, X, weights, attention_w, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
         meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
         H = torch.mm(X, weights)
-        ef = backend().forward_ef(H, *meta)[0]
+        b = backend()
+        ctx.meta = meta
+        ctx.fused = bool(USE_FUSED_AGNN and attention_w.numel() == 1 and hasattr(b, "agnn_fused_forward")
+                         and b.agnn_fused_supported(H, *meta))
+        if ctx.fused:
+            w1 = attention_w.detach().reshape(1).contiguous()
+            out, ef, ef_absmax = b.agnn_fused_forward(H, row_pointers, column_index, w1, blockPartition, edgeToColumn, edgeToRow)
+            ctx.save_for_backward(X, weights, w1, ef, ef_absmax)
+            return out
+        ef = b.forward_ef(H, *meta)[0]
         # reference: mm(ef[:, None], attention_w).T -> [n_heads, E]; a k = 1 matmul is one product per
         # element, so the broadcast below is value-identical and avoids a degenerate GEMM launch
         att = (attention_w.reshape(-1, 1) * ef.unsqueeze(0)).contiguous()
-        out = backend().forward_AGNN(H, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
-        ctx.meta = meta
+        out = b.forward_AGNN(H, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
         ctx.save_for_backward(X, weights, att)
         return out
 
     @staticmethod
     def backward(ctx, d_output):
-        X, weights, att = ctx.saved_tensors
         row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow = ctx.meta
         d_output = d_output.contiguous()
-        g = backend().forward_AGNN(d_output, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
+        b = backend()
+        if ctx.fused:
+            X, weights, w1, ef, ef_absmax = ctx.saved_tensors
+            g, d_w = b.agnn_fused_backward(d_output, row_pointers, column_index, w1, ef, ef_absmax, blockPartition, edgeToColumn, edgeToRow)
+            d_attention_w = d_w.reshape(1, n_heads)
+        else:
+            X, weights, att = ctx.saved_tensors
+            g = b.forward_AGNN(d_output, row_pointers, column_index, att, blockPartition, edgeToColumn, edgeToRow)[0]
+            d_att = b.forward_ef(d_output, *ctx.meta)[0]
+            # reference: mm(d_att[None, :].expand(n_heads, -1), column_index[:, None].float()).T, i.e. the
+            # dot product <d_att, column_index> per head.  As an [n_heads, E] x [E] matrix-vector product:
+            # the 1 x E x 1 GEMM form falls off rocBLAS' fast paths at E ~ 1e8 (30 s per call measured).
+            d_attention_w = torch.mv(d_att[None, :].expand(n_heads, -1), column_index.float()).reshape(1, n_heads)
         d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
         d_weights = tall_tn_mm(X, g)
-        d_att = backend().forward_ef(d_output, *ctx.meta)[0]
-        # reference: mm(d_att[None, :].expand(n_heads, -1), column_index[:, None].float()).T, i.e. the
-        # dot product <d_att, column_index> per head.  As an [n_heads, E] x [E] matrix-vector product:
-        # the 1 x E x 1 GEMM form falls off rocBLAS' fast paths at E ~ 1e8 (30 s per call measured).
-        d_attention_w = torch.mv(d_att[None, :].expand(n_heads, -1), column_index.float()).reshape(1, n_heads)
         return (d_input, d_weights, d_attention_w) + (None,) * 5
 
 

@@ -223,6 +223,98 @@ def test_layers_with_hip_kernels_reproduce_reference_fixture(dev, T):
     assert abs(float(a.grad) - float(f["agnn_dattention_w"])) <= 1e-5 * term_scale
 
 
+FUSED_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n40", "empty_middle_window_n48", "powerlaw_n1000", "citeseer_shape",
+                                            "dense_n3000_deg150", "powerlaw_n12000_deg40")]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+@pytest.mark.parametrize("D", [16, 64, 128, 7, 41, 96])
+def test_fused_agnn_products_equal_the_separate_calls_and_the_oracle(dev, T, case, D):
+    """tcgnn_agnn_forward / tcgnn_agnn_backward (one gather for SDDMM + edge-weighted SpMM) against
+    (a) the oracle composed the way gnn_conv.py:125-153 composes the operators and (b) the separate HIP calls."""
+    name, rp, col = case
+    n, nnz = len(rp) - 1, len(col)
+    if n > 5000 and D in (7, 96):
+        pytest.skip("large graphs: headline widths only")
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    rng = np.random.default_rng(77 * D + n)
+    mag = float(rng.choice([0.05, 1.0, 1.0, 40.0]))
+    H = (rng.standard_normal((n, D)) * mag / np.sqrt(D)).astype(np.float32)
+    dY = rng.standard_normal((n, D)).astype(np.float32)
+    wv = np.float32(rng.choice([0.7, -1.3, 2.5]))
+    tH, tdY = to_dev(dev, H, dY)
+    tw = torch.tensor([wv], device=dev)
+    assert T.agnn_fused_supported(tH, *meta)
+
+    Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
+    ef_sep = T.forward_ef(tH, *meta)[0]
+    assert torch.equal(ef, ef_sep), "fused scores differ from tcgnn_sddmm"
+    assert efmax.view(torch.float32).item() == ef_sep.abs().max().item()
+    att = (tw.view(1, 1) * ef_sep.unsqueeze(0)).contiguous()
+    Y_sep = T.forward_AGNN(tH, trp, tcol, att, tbp, te2c, te2r)[0]
+    # same operand rounding, same accumulation order inside a wavefront's run of tiles; the two kernels cut a window's
+    # tiles into runs differently, so sums may differ by accumulation order only
+    att_np = att.cpu().numpy()[0]
+    Y64, absY = O.spmm_f64(H, rp, col, att_np)
+    ref = O.spmm_val(H, rp, col, att_np, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(Y.cpu().numpy(), ref, Y64, absY, "fused forward Y", mag <= 1.0)
+    assert np.abs(Y.cpu().numpy() - Y_sep.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+
+    G, dw = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
+    G_sep = T.forward_AGNN(tdY, trp, tcol, att, tbp, te2c, te2r)[0]
+    G64, absG = O.spmm_f64(dY, rp, col, att_np)
+    refG = O.spmm_val(dY, rp, col, att_np, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(G.cpu().numpy(), refG, G64, absG, "fused backward G", mag <= 1.0)
+    assert np.abs(G.cpu().numpy() - G_sep.cpu().numpy()).max() <= TIGHT * (absG.max() + 1.0)
+    d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
+    want = float((d_att * col.astype(np.float64)).sum())
+    term_scale = float((np.abs(d_att) * col).sum()) + 1.0
+    assert dw.shape == (1,) and abs(float(dw) - want) <= 1e-6 * term_scale, (float(dw), want, term_scale)
+    # deterministic: a second call returns the same bits
+    G2, dw2 = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
+    assert torch.equal(G, G2) and torch.equal(dw, dw2)
+
+
+def test_fused_agnn_refuses_what_it_does_not_cover(dev, T):
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(300, 6, seed=3)
+    _, meta = meta_for(dev, rp, col)
+    x = torch.randn(300, 160, device=dev)
+    assert not T.agnn_fused_supported(x, *meta)
+    with pytest.raises(RuntimeError, match="not supported"):
+        T.agnn_fused_forward(x, meta[0], meta[1], torch.ones(1, device=dev), *meta[2:])
+    assert c.lib.tcgnn_status_string(6) == b"not supported by the fused entry point"
+    with pytest.raises(RuntimeError, match="one value"):
+        T.agnn_fused_forward(x[:, :16].contiguous(), meta[0], meta[1], torch.ones(2, device=dev), *meta[2:])
+
+
+def test_agnn_layer_gives_the_same_gradients_fused_and_separate(dev, T):
+    import tcgnn_layers as L
+    L.set_backend(T)
+    rp, col = graphs.powerlaw_graph(2000, 30, seed=21)
+    _, meta = meta_for(dev, rp, col)
+    torch.manual_seed(4)
+    X = torch.randn(2000, 50, device=dev)
+    W0 = torch.randn(50, 32, device=dev) / 7.0
+    a0 = torch.tensor([[0.8]], device=dev)
+    dY = torch.randn(2000, 32, device=dev)
+    res = {}
+    for fused in (True, False):
+        L.USE_FUSED_AGNN = fused
+        try:
+            x, w, a = X.clone().requires_grad_(True), W0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+            y = L.TCGNNFunction_AGNN.apply(x, w, a, *meta)
+            y.backward(dY)
+            res[fused] = (y.detach(), x.grad, w.grad, a.grad)
+        finally:
+            L.USE_FUSED_AGNN = True
+    for got, want, what in zip(res[True], res[False], ("Y", "dX", "dW", "d_attention_w")):
+        scale = float(want.abs().max()) + 1.0
+        tol = 2e-5 if what != "d_attention_w" else 2e-4
+        assert got.shape == want.shape and float((got - want).abs().max()) <= tol * scale, what
+
+
 def test_range_robustness_beyond_fp16(dev, T):
     """Values far outside fp16's range (the reference's TF32 has fp32's exponent) survive the
     per-call power-of-two scaling."""
