@@ -194,7 +194,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
  * the separate calls (10-bit mantissa operands, fp32 accumulate); the power-of-two scale of att comes
  * from a bound instead of a pass over E, so results equal the separate calls bit for bit unless an
  * edge weight is more than 2^-20 below that bound.  d_dw is a fixed-order reduction (deterministic).
- * Supported for canonical plans (sorted, duplicate-free rows), D <= 128, E >= 4:
+ * Supported for canonical plans (sorted, duplicate-free rows), D <= 128, E >= 8:
  * tcgnn_agnn_supported() tells; otherwise the calls return TCGNN_ERR_UNSUPPORTED and the caller
  * uses the three separate entry points. */
 int tcgnn_agnn_supported(const tcgnn_plan* plan, int32_t D);

@@ -280,7 +280,7 @@ def forward_ef(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeT
 # ---- additions (not in the reference module): the two products of an AGNN layer in one pass ------------
 
 def agnn_fused_supported(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
-    """True if agnn_fused_forward / agnn_fused_backward cover this graph and width (canonical CSR, D <= 128, E >= 4)."""
+    """True if agnn_fused_forward / agnn_fused_backward cover this graph and width (canonical CSR, D <= 128, E >= 8)."""
     if not (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32) or input.shape[0] == 0 or input.shape[1] == 0:
         return False
     with torch.cuda.device(input.device):

@@ -355,6 +355,9 @@ __device__ __forceinline__ void fill_afrag_table(char* tab) {
 
 // Per-tile metadata travels as ONE 256-byte DMA: lane l < 32 fetches cols[t][l], lanes 32..47
 // mask[t][l-32], lanes 48..63 ebase[t][l-48]; it lands lane-linear in a per-wavefront pad.
+#ifndef TCGNN_META_AUX
+#define TCGNN_META_AUX 0   // cache policy of the metadata stream (bit 1 = nt): A/B experiments
+#endif
 struct MetaSource {
     const char* base;   // this lane's element of tile 0
     int shift;          // log2(bytes per tile) of the array this lane reads
@@ -365,7 +368,7 @@ struct MetaSource {
     }
     __device__ __forceinline__ void dma(int64_t t, uint32_t pad_lds) const {
         const char* src = base + (t << shift);
-        __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)pad_lds, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)pad_lds, 4, 0, TCGNN_META_AUX);
     }
 };
 static constexpr int kPadBytes = 256;
@@ -976,14 +979,15 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs 
 // Fused AGNN products: one gather of a tile's 32 neighbour rows feeds BOTH the edge scores
 // (SDDMM) and the edge-weighted aggregation (SpMM), which the AGNN layer always wants together.
 //
-// Per tile:   S^T = Xc * Xw^T   (MFMA #1: tile columns as rows m, the 16 window rows as columns n, K = D)
-//             lane (g, i) then holds, for window row i, the scores of tile columns 4g..4g+3 and
-//             16+4g..16+4g+3 - exactly an A fragment of MFMA #2 if its eight k slots are NAMED that
-//             way, so no data moves between lanes:
-//             Y  += att * Xc    (MFMA #2: k slot j <-> tile column (j < 4 ? 4g + j : 16 + 4g + j - 4))
-// The gathered rows land lane-linear in LDS (lane (g, i) DMAs halves 32ks + 8g.. of tile column
-// 16sub + i to slot lane*16 of block (sub, ks)); MFMA #1 reads each lane's own slot back, MFMA #2
-// reads the same bytes through ds_read_b64_tr_b16 with the k-slot naming above.  One buffer is
+// Per tile:   S^T = Xc * Xw^T   (MFMA #1, once per half: 16 tile columns as rows m, the 16 window rows as
+//             columns n, K = D).  Row m of half `sub` is tile column 8(m>>2) + 4sub + (m&3), so lane (g, i)
+//             ends up holding, for window row i, the scores of tile columns 8g .. 8g+7 - exactly an A
+//             fragment of MFMA #2 (k slot j <-> tile column 8g + j), and row i's edges inside those eight
+//             columns are ONE run of ef.  No data moves between lanes:
+//             Y  += att * Xc    (MFMA #2)
+// The gathered rows land lane-linear in LDS (lane (g, i) DMAs halves 32ks + 8g.. of row m = i of half
+// sub to slot lane*16 of block (sub, ks)); MFMA #1 reads each lane's own slot back, MFMA #2 reads the
+// same bytes through ds_read_b64_tr_b16.  One buffer is
 // enough: every LDS read of tile t completes before the gather of tile t+1 is issued, and that
 // gather is in flight while tile t is multiplied.
 //   forward  (BWD = false): ef = scores (staged per row, flushed as contiguous runs, as in
@@ -1010,7 +1014,7 @@ struct AgnnArgs {
 };
 
 static constexpr int agnn_wave_lds(int ks, bool bwd) {
-    return 2 * ks * 1024 + kPadBytes + (bwd ? 2048 : 16 * kSddmmStageCap * 4 + 256);
+    return 2 * ks * 1024 + kPadBytes + (bwd ? 2048 : 16 * kSddmmStageCap * 4 + 256);   // backward: two 1 KB edge-value blocks
 }
 
 template <int NT, int WAVES, bool BWD>
@@ -1050,14 +1054,16 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     uint32_t boff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) boff[ks] = (ks * 32 + 8 * g < a.Dpad) ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u;
-    // pad: cols[32] | mask[16] | ebase[16]; this lane: ids of tile columns i and 16+i (for the gather), mask and edge offset of ROW i
-    const uint32_t idaddr[4] = {pad + (uint32_t)i * 4u, pad + 64u + (uint32_t)i * 4u, pad + 128u + (uint32_t)i * 4u, pad + 192u + (uint32_t)i * 4u};
+    // pad: cols[32] | mask[16] | ebase[16]; this lane: ids of the tile columns it gathers for the two halves
+    // (row m = i of half sub is tile column 8(i>>2) + 4sub + (i&3)), mask and edge offset of ROW i
+    const uint32_t pcol = (uint32_t)(8 * (i >> 2) + (i & 3));
+    const uint32_t idaddr[4] = {pad + pcol * 4u, pad + (pcol + 4u) * 4u, pad + 128u + (uint32_t)i * 4u, pad + 192u + (uint32_t)i * 4u};
     uint32_t qaddr[NQ];
 #pragma unroll
     for (int k = 0; k < 2 * KS; ++k) qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
     if constexpr (BWD) { qaddr[2 * KS] = aux + (uint32_t)lane * 16u; qaddr[2 * KS + 1] = aux + 1024u + (uint32_t)lane * 16u; }
-    const uint32_t caddr[2] = {pad + 16u * (uint32_t)g, pad + 64u + 16u * (uint32_t)g};   // ids of my eight tile columns (backward)
-    // transpose reads: this lane addresses k row j = i >> 2 (tile column 4g + j of half h), feature quad q = i & 3 of slice s
+    const uint32_t caddr[2] = {pad + 32u * (uint32_t)g, pad + 32u * (uint32_t)g + 16u};   // ids of my eight tile columns (backward)
+    // transpose reads: this lane addresses k row j = i >> 2 (row m = 4g + j of half h), feature quad q = i & 3 of slice s
     uint32_t raddr[NT][2];
 #pragma unroll
     for (int s = 0; s < NT; ++s)
@@ -1067,7 +1073,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     const uint32_t stg_i = aux + (uint32_t)i * CAP * 4u;
     const uint32_t junk = aux + 16u * CAP * 4u + (uint32_t)lane * 4u;
     const uint32_t flush_base = aux + (uint32_t)lane * 4u;
-    const uint32_t lowq[2] = {(1u << (4 * g)) - 1u, (1u << (16 + 4 * g)) - 1u};         // condensed columns left of my two quads
+    const uint32_t lowq[2] = {(1u << (8 * g)) - 1u, (1u << (8 * g + 4)) - 1u};          // condensed columns left of my two quads
+    const uint32_t halfbits[2] = {0x0f0f0f0fu, 0xf0f0f0f0u};                            // tile columns of each half
 
     floatx4 acc[NT];
 #pragma unroll
@@ -1108,16 +1115,16 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                     __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + (sub * KS + ks) * 1024), 16,
                                                                 (int)cid[sub], (int)boff[ks], 0, 0, 0);
         };
-        struct Cur { uint32_t m, eb; int sh[2]; uintx4 c[2]; };
-        // saved scores of row i inside my two column quads: 4 consecutive floats each, clamped to stay inside ef
+        struct Cur { uint32_t m, eb; int sh; bool wide; uintx4 c[2]; };
+        // saved scores of row i inside my eight tile columns: one run of ef.  Four floats (clamped to stay inside ef)
+        // cover it almost always; a second DMA fetches the next four when some lane's run is longer.
         auto dma_vals = [&](Cur& c) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & lowq[h]);
-                int64_t lo = e0 < a.E - 4 ? e0 : a.E - 4;
-                c.sh[h] = (int)(e0 - lo);
-                __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)(aux + h * 1024), 16, 0, 0);
-            }
+            const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & lowq[0]);
+            int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
+            c.sh = (int)(e0 - lo);
+            c.wide = __any(__popc((c.m >> (8 * g)) & 0xffu) + c.sh > 4);
+            __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)aux, 16, 0, 0);
+            if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo + 4), (LDS_AS void*)(uintptr_t)(aux + 1024), 16, 0, 0);
         };
         auto stage = [&](Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
             wait_vm0();
@@ -1126,7 +1133,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             lds_ids_block<4>(idaddr, v, qaddr[0], q[0]);          // next tile: two row ids, my row's mask and edge offset; + operand 0
             lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands [+ my saved scores]
             Cur nx;
-            nx.m = v[2]; nx.eb = v[3]; nx.sh[0] = nx.sh[1] = 0;
+            nx.m = v[2]; nx.eb = v[3]; nx.sh = 0; nx.wide = false;
             if constexpr (BWD) lds_q_block<2, 0>(caddr, nx.c);
             half4 lo[NT], hi[NT];
             lds_tr_block<NT, 0>(raddr, lo, hi);
@@ -1142,7 +1149,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 S[sub] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (__any(((cur.m >> (16 * sub)) & 0xffffu) != 0u)) {
+                if (__any((cur.m & halfbits[sub]) != 0u)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         S[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, q[sub * KS + ks]), af[ks], S[sub], 0, 0, 0);
@@ -1152,10 +1159,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             half8 a16;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                const uint32_t nib = (cur.m >> (16 * sub + 4 * g)) & 0xfu;
-                const uint32_t base = (uint32_t)__popc(cur.m & lowq[sub]);
-                floatx4 sv;
-                if constexpr (BWD) sv = __builtin_bit_cast(floatx4, q[2 * KS + sub]);
+                const uint32_t nib = (cur.m >> (8 * g + 4 * sub)) & 0xfu;
+                const uint32_t base = (uint32_t)__popc(cur.m & lowq[sub]);          // row i's edges left of this quad
+                const uint32_t inrun = (uint32_t)__popc((cur.m >> (8 * g)) & (sub ? 0xfu : 0u));   // ... of them inside my run
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool on = (nib >> r) & 1u;
@@ -1164,7 +1170,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                     if (two_step) sc *= inv_b;
                     float att;
                     if constexpr (BWD) {
-                        const uint32_t kk = k + (uint32_t)cur.sh[sub];
+                        const uint32_t kk = inrun + k + (uint32_t)cur.sh;          // position in the eight fetched floats
+                        const floatx4 sv = __builtin_bit_cast(floatx4, (kk & 4u) ? q[2 * KS + 1] : q[2 * KS]);
                         const float v01 = (kk & 1u) ? sv[1] : sv[0];
                         const float v23 = (kk & 1u) ? sv[3] : sv[2];
                         att = ((kk & 2u) ? v23 : v01) * wv;
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             uint32_t v[4];
             uintx4 dummy;
             lds_ids_block<4>(idaddr, v, qaddr[0], dummy);
-            cur.m = v[2]; cur.eb = v[3]; cur.sh[0] = cur.sh[1] = 0;
+            cur.m = v[2]; cur.eb = v[3]; cur.sh = 0; cur.wide = false;
             if constexpr (BWD) lds_q_block<2, 0>(caddr, cur.c);
             dma_b(v);
             if constexpr (BWD) dma_vals(cur);
@@ -1506,7 +1513,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
 }
 
 static bool agnn_supported(const tcgnn_plan* plan, int32_t D) {
-    return plan && plan->canonical && D >= 1 && D <= kMaxChunkDims && plan->E >= 4;
+    return plan && plan->canonical && D >= 1 && D <= kMaxChunkDims && plan->E >= 8;
 }
 
 static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_absmax, float* d_Y,
@@ -1515,7 +1522,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     if (!plan || D < 1 || !d_w || !d_absmax || (bwd && !d_dw) || (plan->N > 0 && (!d_X || !d_Y)) || (plan->E > 0 && !d_ef))
         return fail(TCGNN_ERR_INVALID_ARG, "%s: null argument or D < 1", name);
     if (!agnn_supported(plan, D))
-        return fail(TCGNN_ERR_UNSUPPORTED, "%s: needs a canonical plan, D <= %d and E >= 4 (canonical=%d, D=%d, E=%lld)", name,
+        return fail(TCGNN_ERR_UNSUPPORTED, "%s: needs a canonical plan, D <= %d and E >= 8 (canonical=%d, D=%d, E=%lld)", name,
                     kMaxChunkDims, plan->canonical, D, (long long)plan->E);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan);
