@@ -185,6 +185,13 @@ def single_gpu(args):
         att = torch.randn(1, E, device=dev, generator=g)
         extra["sddmm_d%d" % D] = kernel_leg(lambda: TCGNN.forward_ef(X, *meta), sddmm_bytes(n, E, D))
         extra["spmm_agnn_d%d" % D] = kernel_leg(lambda: TCGNN.forward_AGNN(X, rp_d, col_d, att, bp, e2c, e2r), spmm_bytes(n, E, D) + 4 * E)
+        # the two products of an AGNN layer in one pass (what TCGNNFunction_AGNN calls): pair time vs the two legs above
+        wdev = torch.tensor([0.9], device=dev)
+        _, ef_s, efm_s = TCGNN.agnn_fused_forward(X, rp_d, col_d, wdev, bp, e2c, e2r)
+        pair_bytes = sddmm_bytes(n, E, D) + 4 * n * D
+        extra["agnn_fused_fwd_d%d" % D] = kernel_leg(lambda: TCGNN.agnn_fused_forward(X, rp_d, col_d, wdev, bp, e2c, e2r), pair_bytes)
+        extra["agnn_fused_bwd_d%d" % D] = kernel_leg(lambda: TCGNN.agnn_fused_backward(X, rp_d, col_d, wdev, ef_s, efm_s, bp, e2c, e2r), pair_bytes)
+        del ef_s, efm_s
         for d2 in (16, 128):
             X2 = torch.randn(n, d2, device=dev, generator=g)
             extra["spmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward(X2, *meta), spmm_bytes(n, E, d2), reps=10)

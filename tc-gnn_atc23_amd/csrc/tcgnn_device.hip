@@ -1011,13 +1011,18 @@ struct AgnnArgs {
     int32_t N, Nc, row_off, Dpad, D, stride;
     int64_t E;
     const int32_t* rowptr;
+    const uint32_t* bptr;      // range-major walk (MAXW > 0): per-window tile offsets of the column buckets
+    int32_t nbuckets, gsel, nranges, nw, ngroups;
 };
 
 static constexpr int agnn_wave_lds(int ks, bool bwd) {
     return 2 * ks * 1024 + kPadBytes + (bwd ? 2048 : 16 * kSddmmStageCap * 4 + 256);   // backward: two 1 KB edge-value blocks
 }
 
-template <int NT, int WAVES, bool BWD>
+// MAXW = 0: one workgroup per window, each wavefront a contiguous quarter of its tiles.
+// MAXW > 0: persistent wavefronts that own MAXW windows (accumulators in registers) and walk the column
+//           ranges in step, as spmm_blocked_kernel does, so the gathered rows stay L2-resident.
+template <int NT, int WAVES, bool BWD, int MAXW>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = (NT + 1) / 2;
@@ -1027,11 +1032,6 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
-    const int w = a.order[blockIdx.x];
-    const int64_t tb = a.wb_ptr[w], te_w = a.wb_ptr[w + 1];
-    const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
-    int64_t t = tb + wave * chunk;
-    const int64_t te = t + chunk < te_w ? t + chunk : te_w;
     const int64_t stride = a.stride;
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const bool two_step = kx > 63 || kx < -63;                     // score = acc * 2^(-2kx), in two factors if needed
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     if constexpr (BWD) att_bound = fabsf(wv) * __uint_as_float(a.ef_absmax[0]);
     else { const float xm = __uint_as_float(a.hdr[0]); att_bound = fabsf(wv) * (float)a.Dpad * xm * xm; }
     const int ka = scale_exp_from_bits(__float_as_uint(att_bound));
-    const float sa = pow2f(ka);
+    const float c_val = wv * pow2f(ka);   // power-of-two scaling commutes with rounding: fl(x * w) * 2^ka == fl(x * (w * 2^ka))
     const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
@@ -1073,16 +1073,15 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     const uint32_t stg_i = aux + (uint32_t)i * CAP * 4u;
     const uint32_t junk = aux + 16u * CAP * 4u + (uint32_t)lane * 4u;
     const uint32_t flush_base = aux + (uint32_t)lane * 4u;
-    const uint32_t lowq[2] = {(1u << (8 * g)) - 1u, (1u << (8 * g + 4)) - 1u};          // condensed columns left of my two quads
+    const uint32_t low8 = (1u << (8 * g)) - 1u;                                         // condensed columns left of my eight
     const uint32_t halfbits[2] = {0x0f0f0f0fu, 0xf0f0f0f0u};                            // tile columns of each half
 
-    floatx4 acc[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
     uint32_t emax = 0u;
     float dsum = 0.f;
 
-    if (t < te) {
+    // one run: consecutive tiles t .. te-1 of window w, accumulated into acc
+    auto run = [&](const int w, int64_t t, const int64_t te, floatx4 (&acc)[NT]) {
+        if (t >= te) return;
         // B operand of MFMA #1: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
         int64_t arow = (int64_t)w * kWinRows + i;
         arow = arow < a.N ? arow + a.row_off : a.Nc;
@@ -1103,7 +1102,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             for (int r = 0; r < 16; ++r) {
                 const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
                 const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
-                if ((uint32_t)lane < c_r) *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+                if ((uint32_t)lane < c_r) {
+                    *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+                    const uint32_t ab = vals[r] & 0x7fffffffu;           // max |ef| for the backward call's scale
+                    emax = ab > emax ? ab : emax;
+                }
             }
             cnt = 0u; rstart = ~0u;
         };
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         // saved scores of row i inside my eight tile columns: one run of ef.  Four floats (clamped to stay inside ef)
         // cover it almost always; a second DMA fetches the next four when some lane's run is longer.
         auto dma_vals = [&](Cur& c) {
-            const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & lowq[0]);
+            const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & low8);
             int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
             c.sh = (int)(e0 - lo);
             c.wide = __any(__popc((c.m >> (8 * g)) & 0xffu) + c.sh > 4);
@@ -1155,35 +1158,44 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                         S[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, q[sub * KS + ks]), af[ks], S[sub], 0, 0, 0);
                 }
             }
-            // ---- edge weights of row i for my eight tile columns
+            // ---- edge weights of row i for my eight tile columns (branch-free; 10-bit RNA rounding done in integer
+            //      arithmetic, after which the round-toward-zero pack conversion is exact)
+            const uint32_t byte = (cur.m >> (8 * g)) & 0xffu;
+            uint32_t kpos[8];                                   // rank of column j among row i's edges inside my run
+            kpos[0] = 0u;
+#pragma unroll
+            for (int j = 1; j < 8; ++j) kpos[j] = kpos[j - 1] + ((byte >> (j - 1)) & 1u);
+            [[maybe_unused]] const uint32_t spos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);
+            uint32_t rb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool on = (byte >> j) & 1u;
+                const float sraw = S[j >> 2][j & 3];
+                float att_s;
+                if constexpr (BWD) {
+                    const uint32_t kk = kpos[j] + (uint32_t)cur.sh;                  // position in the eight fetched floats
+                    const floatx4 sv = __builtin_bit_cast(floatx4, (kk & 4u) ? q[2 * KS + 1] : q[2 * KS]);
+                    const float v01 = (kk & 1u) ? sv[1] : sv[0];
+                    const float v23 = (kk & 1u) ? sv[3] : sv[2];
+                    att_s = ((kk & 2u) ? v23 : v01) * c_val;                         // = fl32(w * ef) * 2^ka
+                    float sc = sraw * inv_a;
+                    if (two_step) sc *= inv_b;
+                    dsum += on ? sc * (float)(int32_t)cur.c[j >> 2][j & 3] : 0.0f;
+                } else {
+                    float sc = sraw * inv_a;
+                    if (two_step) sc *= inv_b;
+                    lds_write_b32(on ? spos + (kpos[j] << 2) : junk, sc);
+                    att_s = sc * c_val;                                              // = fl32(w * ef) * 2^ka
+                }
+                const uint32_t u = on ? __float_as_uint(att_s) : 0u;
+                rb[j] = (u + 0x1000u) & 0xffffe000u;
+            }
             half8 a16;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const uint32_t nib = (cur.m >> (8 * g + 4 * sub)) & 0xfu;
-                const uint32_t base = (uint32_t)__popc(cur.m & lowq[sub]);          // row i's edges left of this quad
-                const uint32_t inrun = (uint32_t)__popc((cur.m >> (8 * g)) & (sub ? 0xfu : 0u));   // ... of them inside my run
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool on = (nib >> r) & 1u;
-                    const uint32_t k = (uint32_t)__popc(nib & ((1u << r) - 1u));
-                    float sc = S[sub][r] * inv_a;
-                    if (two_step) sc *= inv_b;
-                    float att;
-                    if constexpr (BWD) {
-                        const uint32_t kk = inrun + k + (uint32_t)cur.sh;          // position in the eight fetched floats
-                        const floatx4 sv = __builtin_bit_cast(floatx4, (kk & 4u) ? q[2 * KS + 1] : q[2 * KS]);
-                        const float v01 = (kk & 1u) ? sv[1] : sv[0];
-                        const float v23 = (kk & 1u) ? sv[3] : sv[2];
-                        att = ((kk & 2u) ? v23 : v01) * wv;
-                        dsum += on ? sc * (float)(int32_t)cur.c[sub][r] : 0.0f;
-                    } else {
-                        lds_write_b32(on ? stg_i + ((cnt + base + k) << 2) : junk, sc);
-                        att = sc * wv;
-                        const uint32_t ab = __float_as_uint(sc) & 0x7fffffffu;
-                        emax = (on && ab > emax) ? ab : emax;
-                    }
-                    a16[4 * sub + r] = on ? to_half_rna(att * sa) : (_Float16)0.0f;
-                }
+            for (int j = 0; j < 8; j += 2) {
+                const auto pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rb[j]), __uint_as_float(rb[j + 1]));
+                a16[j] = (_Float16)pk[0];
+                a16[j + 1] = (_Float16)pk[1];
             }
             // ---- aggregation
 #pragma unroll
@@ -1220,6 +1232,58 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         if (tn < te) meta.dma(tn, pad);
         while (stage(cur, t, tn)) {}
         wait_vm0();
+    };
+
+    const float inv1 = pow2f(-kx), inv2 = pow2f(-ka);
+    auto store_rows = [&](const int w, const int s, const floatx4& v) {
+        const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
+        const int colg = 16 * s + i;
+        if (colg < a.D) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
+        }
+    };
+
+    [[maybe_unused]] int w0 = 0;
+    [[maybe_unused]] floatx4 acc0[NT];
+    if constexpr (MAXW == 0) {
+        w0 = a.order[blockIdx.x];
+        const int64_t tb = a.wb_ptr[w0], te_w = a.wb_ptr[w0 + 1];
+        const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
+        const int64_t t0 = tb + wave * chunk;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc0[s] = floatx4{0.f, 0.f, 0.f, 0.f};
+        run(w0, t0, t0 + chunk < te_w ? t0 + chunk : te_w, acc0);
+    } else {
+        const int gw = blockIdx.x * WAVES + wave, gwn = gridDim.x * WAVES;
+        for (int grp = gw; grp < a.ngroups; grp += gwn) {
+            int wj[MAXW];
+            int64_t tbj[MAXW];
+            floatx4 acc[MAXW][NT];
+#pragma unroll
+            for (int j = 0; j < MAXW; ++j) {
+                const int idx = grp + j * a.ngroups;   // strided picks from the heaviest-first order: balanced groups
+                wj[j] = idx < a.nw ? __builtin_amdgcn_readfirstlane(a.order[idx]) : -1;
+                tbj[j] = wj[j] >= 0 ? a.wb_ptr[wj[j]] : 0;
+#pragma unroll
+                for (int s = 0; s < NT; ++s) acc[j][s] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int r = 0; r < a.nranges; ++r) {
+#pragma unroll
+                for (int j = 0; j < MAXW; ++j) {
+                    if (wj[j] < 0) continue;
+                    const uint32_t* bp = a.bptr + (int64_t)wj[j] * (a.nbuckets + 1);
+                    run(wj[j], tbj[j] + bp[r * a.gsel], tbj[j] + bp[(r + 1) * a.gsel], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MAXW; ++j) {
+                if (wj[j] < 0) continue;
+#pragma unroll
+                for (int s = 0; s < NT; ++s) store_rows(wj[j], s, acc[j][s]);
+            }
+        }
     }
 
     if constexpr (BWD) {
@@ -1242,38 +1306,26 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         if (lane == 0 && emax != 0u) atomicMax(a.ef_absmax, emax);
     }
 
-    // ---- combine the wavefronts' partial sums in a fixed order and store
-    const float inv1 = pow2f(-kx), inv2 = pow2f(-ka);
-    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
-    if constexpr (WAVES > 1) {
-        __syncthreads(); // every wave is done with its LDS
-        floatx4* red = reinterpret_cast<floatx4*>(smem);
+    // ---- per-window workgroups: combine the wavefronts' partial sums in a fixed order and store
+    if constexpr (MAXW == 0) {
+        if constexpr (WAVES > 1) {
+            __syncthreads(); // every wave is done with its LDS
+            floatx4* red = reinterpret_cast<floatx4*>(smem);
 #pragma unroll
-        for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
-        __syncthreads();
-        for (int s = wave; s < NT; s += WAVES) {
-            floatx4 v = red[s * 64 + lane];
+            for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc0[s];
+            __syncthreads();
+            for (int s = wave; s < NT; s += WAVES) {
+                floatx4 v = red[s * 64 + lane];
 #pragma unroll
-            for (int ww = 1; ww < WAVES; ++ww) {
-                const floatx4 o = red[(ww * NT + s) * 64 + lane];
-                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                for (int ww = 1; ww < WAVES; ++ww) {
+                    const floatx4 o = red[(ww * NT + s) * 64 + lane];
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                store_rows(w0, s, v);
             }
-            const int colg = 16 * s + i;
-            if (colg < a.D) {
+        } else {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const int colg = 16 * s + i;
-            if (colg < a.D) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii] * inv1 * inv2;
-            }
+            for (int s = 0; s < NT; ++s) store_rows(w0, s, acc0[s]);
         }
     }
 }
@@ -1394,11 +1446,12 @@ static hipError_t launch_sddmm_ks(int ks, const SddmmArgs& args, int nwg, hipStr
     return hipGetLastError();
 }
 
-template <int WAVES, bool BWD>
+static constexpr int kAgnnMaxW = 2;   // windows owned by a wavefront of the range-major fused kernel
+template <int WAVES, bool BWD, int MAXW>
 static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t stream) {
     const dim3 grid((unsigned)nwg), block(WAVES * 64);
     const size_t lds = (size_t)WAVES * agnn_wave_lds((nt + 1) / 2, BWD);
-#define TCGNN_AGNN_CASE(n) case n: hipLaunchKernelGGL((agnn_kernel<n, WAVES, BWD>), grid, block, lds, stream, args); break;
+#define TCGNN_AGNN_CASE(n) case n: hipLaunchKernelGGL((agnn_kernel<n, WAVES, BWD, MAXW>), grid, block, lds, stream, args); break;
     switch (nt) {
         TCGNN_AGNN_CASE(1) TCGNN_AGNN_CASE(2) TCGNN_AGNN_CASE(3) TCGNN_AGNN_CASE(4)
         TCGNN_AGNN_CASE(5) TCGNN_AGNN_CASE(6) TCGNN_AGNN_CASE(7) TCGNN_AGNN_CASE(8)
@@ -1541,17 +1594,39 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         return TCGNN_OK;
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
-               plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr};
+               plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0};
     const int nt = dpad / 16;
+    const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
+    // The range-major variant exists and is bit-compatible, but measured slower for the fused kernel on the Reddit shape
+    // (D=64: 1.87 vs 1.80 ms forward, 2.39 vs 1.90 ms backward; D=32 forward is the one exception, 1.28 vs 1.55): the
+    // fused loop is bound by issue slots and wavefront count (PMC: VALU+MFMA ~60 % of SIMD time, 3 instead of 4 waves
+    // per SIMD with the extra accumulators), not by gather locality.  Only on request (mode 2).
+    const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0;
+    int nwg = plan->nw_eff;
     {
         KernelTimer timer(plan, stream);
         hipError_t e;
-        if (plan->waves == 4) e = bwd ? launch_agnn<4, true>(nt, a, plan->nw_eff, stream) : launch_agnn<4, false>(nt, a, plan->nw_eff, stream);
-        else                  e = bwd ? launch_agnn<1, true>(nt, a, plan->nw_eff, stream) : launch_agnn<1, false>(nt, a, plan->nw_eff, stream);
+        if (blocked) {
+            size_t range_bytes = 4 * kRangeTargetBytes;
+            if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
+            int nranges = 1;
+            while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
+            a.nranges = nranges;
+            a.gsel = plan->nbuckets / nranges;
+            a.ngroups = (plan->nw_eff + kAgnnMaxW - 1) / kAgnnMaxW;
+            const int lds_wg = 4 * agnn_wave_lds((nt + 1) / 2, bwd);
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 3 : 2, (160 * 1024) / lds_wg));
+            nwg = std::min((a.ngroups + 3) / 4, plan->num_cus * per_cu);
+            e = bwd ? launch_agnn<4, true, kAgnnMaxW>(nt, a, nwg, stream) : launch_agnn<4, false, kAgnnMaxW>(nt, a, nwg, stream);
+        } else if (plan->waves == 4) {
+            e = bwd ? launch_agnn<4, true, 0>(nt, a, nwg, stream) : launch_agnn<4, false, 0>(nt, a, nwg, stream);
+        } else {
+            e = bwd ? launch_agnn<1, true, 0>(nt, a, nwg, stream) : launch_agnn<1, false, 0>(nt, a, nwg, stream);
+        }
         HIP_TRY(e);
     }
     if (bwd) {
-        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, plan->nw_eff, d_dw);
+        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nwg, d_dw);
         HIP_TRY(hipGetLastError());
     }
     return TCGNN_OK;

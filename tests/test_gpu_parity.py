@@ -276,6 +276,48 @@ def test_fused_agnn_products_equal_the_separate_calls_and_the_oracle(dev, T, cas
     assert torch.equal(G, G2) and torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("D", [16, 64, 41, 128])
+def test_fused_agnn_range_major_walk_equals_per_window_walk(dev, T, D):
+    """The persistent range-major variant of the fused kernel (picked automatically for big feature matrices) forced on
+    a graph the oracle can handle: same scores bit for bit, same aggregation up to accumulation order, same d_w."""
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(16448, 180, seed=12)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    assert T.plan_info(*meta)["column_buckets"] > 0
+    rng = np.random.default_rng(D + 5)
+    H = (rng.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
+    dY = rng.standard_normal((n, D)).astype(np.float32)
+    tH, tdY = to_dev(dev, H, dY)
+    tw = torch.tensor([1.7], device=dev)
+    out = {}
+    try:
+        for mode in (1, 2):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
+            G, dw = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
+            out[mode] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax.item(), G.cpu().numpy(), float(dw))
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    ef_ref = O.sddmm(H, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    att = (np.float32(1.7) * out[1][1]).astype(np.float32)
+    Y64, absY = O.spmm_f64(H, rp, col, att)
+    G64, absG = O.spmm_f64(dY, rp, col, att)
+    refY = O.spmm_val(H, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    refG = O.spmm_val(dY, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
+    want = float((d_att * col).sum()); term_scale = float((np.abs(d_att) * col).sum()) + 1.0
+    assert np.array_equal(out[1][1], out[2][1]) and out[1][2] == out[2][2]
+    for mode in (1, 2):
+        Y, ef, _, G, dw = out[mode]
+        ef64, absef = O.sddmm_f64(H, rp, col)
+        assert_parity(ef, ef_ref, ef64, absef, "scores mode %d" % mode)
+        assert_parity(Y, refY, Y64, absY, "Y mode %d" % mode)
+        assert_parity(G, refG, G64, absG, "G mode %d" % mode)
+        assert abs(dw - want) <= 1e-6 * term_scale
+
+
 def test_fused_agnn_refuses_what_it_does_not_cover(dev, T):
     import tcgnn_capi as c
     rp, col = graphs.uniform_graph(300, 6, seed=3)

@@ -25,7 +25,14 @@ for D in (64, 16, 32, 128):
     t_sd, ef = timed(lambda: TCGNN.forward_ef(X, *meta)[0])
     att = (w.view(1, 1) * ef.unsqueeze(0)).contiguous()
     t_sv, Y = timed(lambda: TCGNN.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0])
-    t_ff, (Yf, eff, efm) = timed(lambda: TCGNN.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r))
-    t_fb, (Gf, dw) = timed(lambda: TCGNN.agnn_fused_backward(dY, rp, col, w, eff, efm, bp, e2c, e2r))
-    print("D=%3d  sddmm %.3f + spmm_val %.3f = %.3f ms | fused fwd %.3f  bwd %.3f ms | ef equal %s  Y maxdiff %.2e (max |Y| %.2e)" % (
-        D, t_sd, t_sv, t_sd + t_sv, t_ff, t_fb, torch.equal(ef, eff), (Y - Yf).abs().max().item(), Y.abs().max().item()))
+    import tcgnn_capi as c
+    fused = {}
+    for mode in (1, 2):
+        c.lib.tcgnn_set_spmm_mode(mode)
+        t_ff, (Yf, eff, efm) = timed(lambda: TCGNN.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r))
+        t_fb, (Gf, dw) = timed(lambda: TCGNN.agnn_fused_backward(dY, rp, col, w, eff, efm, bp, e2c, e2r))
+        fused[mode] = (t_ff, t_fb, Yf, eff, float(dw))
+    c.lib.tcgnn_set_spmm_mode(0)
+    print("D=%3d  sddmm %.3f + spmm_val %.3f = %.3f ms | fused per-window fwd %.3f bwd %.3f | range-major fwd %.3f bwd %.3f ms | ef equal %s  Y maxdiff %.2e (max |Y| %.2e) dw %.6e %.6e" % (
+        D, t_sd, t_sv, t_sd + t_sv, fused[1][0], fused[1][1], fused[2][0], fused[2][1], torch.equal(ef, fused[2][3]) and torch.equal(ef, fused[1][3]),
+        (Y - fused[2][2]).abs().max().item(), Y.abs().max().item(), fused[1][4], fused[2][4]))
