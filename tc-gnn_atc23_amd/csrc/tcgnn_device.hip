@@ -1103,7 +1103,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
                 const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
                 if ((uint32_t)lane < c_r) {
+#ifndef TCGNN_EXPERIMENT_NO_EF_STORE
                     *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+#endif
                     const uint32_t ab = vals[r] & 0x7fffffffu;           // max |ef| for the backward call's scale
                     emax = ab > emax ? ab : emax;
                 }
@@ -1303,7 +1305,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     } else {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)emax, off, 64); emax = o > emax ? o : emax; }
-        if (lane == 0 && emax != 0u) atomicMax(a.ef_absmax, emax);
+        // one word for the whole launch: 600k same-address atomics serialise in one L2 channel (12 ns each - they cost
+        // 3 ms on the ogbn-products shape).  The running maximum stops growing after a handful of wavefronts, so look first.
+        if (lane == 0 && emax != 0u && emax > __hip_atomic_load(a.ef_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.ef_absmax, emax);
     }
 
     // ---- per-window workgroups: combine the wavefronts' partial sums in a fixed order and store

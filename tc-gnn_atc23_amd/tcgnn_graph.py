@@ -73,6 +73,20 @@ SHAPES = {  # name: (N, nnz target, in_dim, classes) - SURVEY.md 8(d)
     "pubmed": (19717, 88648, 500, 3),
     "reddit": (232965, 114615892, 602, 41),
     "ogbn-products": (2449029, 123718280, 100, 47),
+    # The reference's artifact graphs (1_bench_gcn.py / 2_tcgnn_single_kernel.py dataset lists give dim and classes;
+    # the .npz files are not in the tree).  N and nnz are the node / edge counts of the TC-GNN paper's dataset table,
+    # used for same-SIZE synthetic stand-ins (tools/bench_artifact_shapes.py) - real graphs have more locality.
+    "ppi": (56944, 818716, 50, 121),
+    "PROTEINS_full": (43471, 162088, 29, 2),
+    "OVCAR-8H": (1890931, 3946402, 66, 2),
+    "Yeast": (1714644, 3636546, 74, 2),
+    "DD": (334925, 1686092, 89, 2),
+    "SW-620H": (1889971, 3944206, 66, 2),
+    "amazon0505": (410236, 4878875, 96, 22),
+    "artist": (50515, 1638396, 100, 12),
+    "com-amazon": (334863, 1851744, 96, 22),
+    "soc-BlogCatalog": (88784, 2093195, 128, 39),
+    "amazon0601": (403394, 3387388, 96, 22),
 }
 
 

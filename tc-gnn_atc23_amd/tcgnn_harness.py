@@ -105,7 +105,7 @@ def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, e
     for _ in range(epochs):
         loss = train()
     torch.cuda.synchronize()
-    return {"train_ms": (time.perf_counter() - start) * 1e3 / max(epochs, 1), "final_loss": float(loss)}
+    return {"train_ms": (time.perf_counter() - start) * 1e3 / max(epochs, 1), "final_loss": float(loss.detach())}
 
 
 def run(args, quiet=False):
