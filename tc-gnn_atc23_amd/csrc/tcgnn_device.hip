@@ -740,9 +740,12 @@ struct SddmmArgs {
 // LDS of one SDDMM wavefront: two operand buffers, the metadata pad, the output staging area
 // (16 rows x kSddmmStageCap floats) and 256 bytes of junk slots for lanes that have nothing to stage.
 static constexpr int kSddmmStageCap = 64;
+#ifndef TCGNN_SDDMM_NBUF
+#define TCGNN_SDDMM_NBUF(ks) ((ks) <= 2 ? 2 : 1)
+#endif
 // Operand buffers: two (gather of the next tile under the multiply of this one) up to D = 64; one beyond,
 // where LDS would otherwise allow a single workgroup per CU (latency is then hidden by wavefront count only).
-static constexpr int sddmm_nbuf(int ks) { return ks <= 2 ? 2 : 1; }
+static constexpr int sddmm_nbuf(int ks) { return TCGNN_SDDMM_NBUF(ks); }
 static constexpr int sddmm_wave_lds(int ks) { return sddmm_nbuf(ks) * (2 * ks * 1024) + kPadBytes + 16 * kSddmmStageCap * 4 + 256; }
 
 // KS = number of 32-wide k steps (D <= 32*KS <= 128).  The 16 window rows (MFMA A operand) stay in
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     const int64_t wrow = (int64_t)w * kWinRows;
     const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
     char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
+    bool flush_pending = false;
     uint32_t cnt[4] = {0u, 0u, 0u, 0u};                          // staged results of rows 4g .. 4g+3
     uint32_t rstart[4] = {~0u, ~0u, ~0u, ~0u};                   // window-relative ef position of each row's first staged result
     auto flush = [&]() {
@@ -848,6 +852,9 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
             dma_b(cid, (NB == 2 ? (BUF ^ 1) : 0) * BUF_BYTES);   // (single buffer: its reads above have completed)
             if (tnn < te) meta.dma(tnn, pad);
         }
+        // A flush decided at the end of the previous tile is issued HERE, right behind the gather: its stores then have as
+        // long to complete as the gather before the next wait (issued after the multiply they held that wait up).
+        if (flush_pending) { flush(); flush_pending = false; }
         // ---- tile tcur
         const uint32_t mm[4] = {cur.m4[0], cur.m4[1], cur.m4[2], cur.m4[3]};
         const uint32_t e0 = (uint32_t)e_w0;   // window-relative edge positions (a window holds far fewer than 2^32 edges)
@@ -881,7 +888,8 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
         }
         // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
         const uint32_t fullest = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
-        if (!more || __any(fullest > (uint32_t)(CAP - 32))) flush();
+        if (!more) flush();
+        else flush_pending = __any(fullest > (uint32_t)(CAP - 32));
         cur.m4 = m4n;
         cur.eb4 = q[0];
         tcur = tn;
@@ -1093,6 +1101,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
         char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
         uint32_t cnt = 0u, rstart = ~0u;                           // staged results of row i / window-relative position of the first
+        [[maybe_unused]] bool flush_pending = false;
 
         auto flush = [&]() {
             uint32_t vals[16];
@@ -1148,6 +1157,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 dma_b(v);
                 if constexpr (BWD) dma_vals(nx);
                 if (tnn < te) meta.dma(tnn, pad);
+            }
+            if constexpr (!BWD) {   // (see sddmm_kernel: a pending flush goes right behind the gather)
+                if (flush_pending) { flush(); flush_pending = false; }
             }
             // ---- tile tcur: scores
             floatx4 S[2];
@@ -1209,7 +1221,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 if (rstart == ~0u && cur.m != 0u) rstart = cur.eb - (uint32_t)e_w0;
                 cnt += (uint32_t)__popc(cur.m);
                 // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
-                if (!more || __any(cnt > (uint32_t)(CAP - 32))) flush();
+                if (!more) flush();
+                else flush_pending = __any(cnt > (uint32_t)(CAP - 32));
             }
             cur = nx;
             tcur = tn;
