@@ -68,7 +68,7 @@ typedef struct tcgnn_plan_info {
     int32_t canonical;       /* 1 if every CSR row is strictly increasing (scipy canonical form) */
     int32_t waves_per_window;/* workgroup shape the launcher picked (1 or 4 wavefronts) */
     int32_t column_buckets;  /* > 0: the plan carries the bucket table of the range-blocked SpMM walk */
-    int32_t reserved;
+    int32_t lds_ranges;      /* > 0: the plan carries the cell stream of the LDS-resident column-range SpMM */
 } tcgnn_plan_info;
 
 int tcgnn_abi_version(void);
@@ -142,8 +142,10 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
 
 /* Tuning / test aid: which SpMM walk tcgnn_spmm and tcgnn_spmm_val use.  0 = automatic (default;
  * range-blocked when the fp16 image of X exceeds the L2 and the windows are long), 1 = always the
- * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table.  Process-wide;
- * the environment variable TCGNN_SPMM_MODE sets the initial value. */
+ * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table, 3 = the
+ * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
+ * plan was created without one).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
+ * initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
 
 /* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While

@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <type_traits>
@@ -69,6 +70,11 @@ struct tcgnn_plan {
     uint32_t* d_bptr = nullptr;   // [nw_eff][nbuckets + 1] tile offset of the first tile whose first column is in bucket >= k
     int32_t num_cus = 256;
     size_t bytes = 0;
+    // cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc); lds_nranges == 0: not built
+    int32_t lds_nranges = 0, lds_nwg = 0;
+    int64_t lds_tiles = 0;
+    uint32_t* d_cell_ptr = nullptr;    // [lds_nwg * lds_nranges * 64 + 1] tile offset of cell (workgroup, range, wavefront, window slot)
+    uint32_t* d_cell_tiles = nullptr;  // [lds_tiles][32] 32 u16 row ids local to the range + 16 mask words
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
     mutable std::vector<hipEvent_t> ev;
     mutable int ev_used = 0;
@@ -718,6 +724,8 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
         }
     }
 }
+
+#include "tcgnn_lds_spmm.inc"
 
 // ------------------------------------------------------------------------------------------
 // SDDMM:  ef[e] = <X16[row e], X16[col e]>
@@ -1479,6 +1487,7 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
     return hipGetLastError();
 }
 
+static int g_lds_dbg = [] { const char* e = getenv("TCGNN_LDS_DBG"); return e ? atoi(e) : 0; }();
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
@@ -1535,6 +1544,56 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     return TCGNN_OK;
 }
 
+// Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
+// condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
+static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (p->lds_nranges > 0) return TCGNN_OK;
+    const int nw = p->nw_eff;
+    if (nw <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
+    const int nranges = (p->Nc + kLdsRows - 1) / kLdsRows;
+    const int per_wg = kLdsWaves * kLdsMaxW;
+    int nwg = (nw + per_wg - 1) / per_wg;
+    if (nwg < p->num_cus) nwg = std::max(nwg, std::min(p->num_cus, (nw + kLdsWaves - 1) / kLdsWaves));   // spread over every CU
+    const int64_t ncell = (int64_t)nwg * nranges * per_wg;
+    uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
+    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); return rc; };
+    hipError_t e = hipMalloc(&d_cnt, (size_t)(ncell + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
+    const int64_t nthreads = (int64_t)nw * nranges;
+    hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, nw, nwg,
+                       nranges, p->Nc, d_cnt, d_firstq);
+    std::vector<uint32_t> cnt((size_t)ncell + 1);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
+    uint64_t run = 0;
+    for (size_t k = 0; k < cnt.size(); ++k) { const uint32_t c = cnt[k]; cnt[k] = (uint32_t)run; run += c; }
+    if (run >= (1ull << 32)) return bail(fail(TCGNN_ERR_BAD_GRAPH, "LDS-range SpMM: %llu tiles overflow the 32-bit cell table", (unsigned long long)run));
+    const int64_t ntiles = (int64_t)run;
+    const int64_t nwords = std::max<int64_t>(ntiles, 1) * kCellWords;
+    e = hipMalloc(&d_tiles, (size_t)nwords * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
+    hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
+                       d_cnt, d_firstq, d_tiles);
+    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `cnt` must outlive its copy
+    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
+    (void)hipFree(d_firstq);
+    p->d_cell_ptr = d_cnt; p->d_cell_tiles = d_tiles;
+    p->lds_nwg = nwg; p->lds_tiles = ntiles;
+    p->bytes += (size_t)(ncell + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t);
+    p->lds_nranges = nranges;
+    return TCGNN_OK;
+}
+
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
                     void* ws, size_t ws_bytes, void* stream_v) {
     if (!plan || D < 1 || (plan->N > 0 && (!d_X || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
@@ -1557,7 +1616,19 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked
+    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges
+    if (!d_val && (mode == 3 || (mode == 0 && plan->lds_nranges > 0))) {
+        if (mode == 3 && plan->lds_nranges == 0) {   // forced on a plan built without the cell stream (tests, tools): build it now
+            const int brc = build_lds_cells(const_cast<tcgnn_plan*>(plan), stream);
+            if (brc) return brc;
+        }
+        SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, pitch, 0, plan->Nc + 1,
+                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg};
+        const int lfull = dpad / kLdsChunkDims, lrem = (dpad % kLdsChunkDims) / 16;
+        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(4, l, lfull, stream)); }
+        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(lrem, l, 1, stream)); }
+        return TCGNN_OK;
+    }
     const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || x16_bytes > kBlockedMinBytes);
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
@@ -1671,6 +1742,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
+    (void)hipFree(plan->d_cell_ptr); (void)hipFree(plan->d_cell_tiles);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -1783,12 +1855,12 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
     info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
     info->canonical = plan->canonical; info->waves_per_window = plan->waves;
-    info->column_buckets = plan->nbuckets; info->reserved = 0;
+    info->column_buckets = plan->nbuckets; info->lds_ranges = plan->lds_nranges;
     return TCGNN_OK;
 }
 
 int tcgnn_set_spmm_mode(int32_t mode) {
-    if (mode < 0 || mode > 2) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain) or 2 (range-blocked)");
+    if (mode < 0 || mode > 3) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked) or 3 (LDS-resident ranges)");
     g_spmm_mode = mode;
     return TCGNN_OK;
 }

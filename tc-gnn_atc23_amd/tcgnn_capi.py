@@ -25,7 +25,7 @@ _i32, _i64, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
 class PlanInfo(ctypes.Structure):
     _fields_ = [("num_nodes", _i32), ("num_windows", _i32), ("num_edges", _i64), ("tc_blocks", _i64),
                 ("wide_blocks", _i64), ("plan_bytes", _i64), ("canonical", _i32), ("waves_per_window", _i32),
-                ("column_buckets", _i32), ("reserved", _i32)]
+                ("column_buckets", _i32), ("lds_ranges", _i32)]
 
 
 class TileStats(ctypes.Structure):

@@ -276,6 +276,37 @@ def test_fused_agnn_products_equal_the_separate_calls_and_the_oracle(dev, T, cas
     assert torch.equal(G, G2) and torch.equal(dw, dw2)
 
 
+
+@pytest.mark.parametrize("D", [16, 32, 41, 64, 100, 128, 160])
+@pytest.mark.parametrize("shape", ["dense", "ragged"])
+def test_lds_resident_range_kernel_matches_oracle_and_plain_walk(dev, T, D, shape):
+    """The LDS-resident column-range SpMM (every workgroup streams each 504-row range of the fp16 image into LDS and
+    reads the MFMA B operand out of it; chosen automatically for dense graphs like Reddit) is forced here on
+    graphs small enough for the oracle: several ranges, windows with no edge in some ranges, a ragged last
+    window, a last range shorter than 504 rows, and more than one 64-column pass."""
+    import tcgnn_capi as c
+    if shape == "dense":
+        rp, col = graphs.uniform_graph(4100, 150, seed=21)       # 9 ranges, ~18 distinct columns per cell
+    else:
+        rp, col = graphs.powerlaw_graph(2061, 9.0, seed=22)     # N % 16 = 13, N % 504 = 45, hubs with > 6 tiles per range
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 3)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    (tX,) = to_dev(dev, X)
+    out = {}
+    try:
+        for mode in (1, 3):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            out[mode] = T.forward(tX, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy()
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    assert T.plan_info(trp, tcol, tbp, te2c, te2r)["lds_ranges"] == (n + 503) // 504
+    Y64, absY = O.spmm_f64(X, rp, col)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    for mode in (1, 3):
+        assert_parity(out[mode], ref, Y64, absY, "spmm mode %d" % mode)
+
 @pytest.mark.parametrize("D", [16, 64, 41, 128])
 def test_fused_agnn_range_major_walk_equals_per_window_walk(dev, T, D):
     """The persistent range-major variant of the fused kernel (picked automatically for big feature matrices) forced on

@@ -24,9 +24,10 @@ for D in (64, 16, 32, 128, 41):
     res = {}
     for name, fn in (("spmm", lambda: TCGNN.forward(X, *meta)[0]), ("spmm_val", lambda: TCGNN.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0])):
         outs = {}
-        times = {1: [], 2: []}
+        modes = (1, 2, 3) if name == "spmm" else (1, 2)
+        times = {m: [] for m in modes}
         for rnd in range(3):
-            for mode in (1, 2):
+            for mode in modes:
                 c.check(c.lib.tcgnn_set_spmm_mode(mode), "mode")
                 fn(); TCGNN.kernel_timing(*meta, max_calls=8)
                 for _ in range(8):
@@ -38,4 +39,7 @@ for D in (64, 16, 32, 128, 41):
         scale = outs[1].abs().max().item()
         print("D=%3d %-8s plain %.3f ms (min %.3f)  blocked %.3f ms (min %.3f)  speed-up %.2fx   max|diff| %.2e (scale %.1f)" % (
             D, name, np.median(times[1]), np.min(times[1]), np.median(times[2]), np.min(times[2]), np.median(times[1]) / np.median(times[2]), diff, scale))
+        if 3 in modes:
+            print("      %-8s LDS-resident ranges %.3f ms (min %.3f)  vs blocked %.2fx   max|diff vs plain| %.2e" % (
+                name, np.median(times[3]), np.min(times[3]), np.median(times[2]) / np.median(times[3]), (outs[1] - outs[3]).abs().max().item()))
 c.lib.tcgnn_set_spmm_mode(0)
