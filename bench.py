@@ -153,6 +153,8 @@ def single_gpu(args):
         pitch *= 2
     blocked = info["column_buckets"] > 0 and (n + 1) * pitch * 2 > (6 << 20)   # the launcher's rule (tcgnn_device.hip run_spmm)
     kname = ("spmm_blocked_kernel<NT=%d,MAXW=%d>" % (nt, 4 if nt <= 4 else 2)) if blocked else ("spmm_kernel<NT=%d,WAVES=%d>" % (nt, info["waves_per_window"]))
+    if info.get("lds_ranges", 0) > 0:   # dense graph: the LDS-resident column-range kernel (64 feature columns per pass)
+        kname = "spmm_lds_kernel<NT=%d>" % min(4, nt)
     out = {
         "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
         "value": round(gteps, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -160,7 +162,7 @@ def single_gpu(args):
         "dtype": "f16 operands (TF32-equivalent rounding), f32 accumulate, f32 I/O", "data": "synthetic",
         "config": {"workload": workload, "graph": "seeded uniform symmetric, canonical CSR", "tc_blocks_16x8": info["tc_blocks"],
                    "reddit_real_tc_blocks_16x8": 13566510, "wide_blocks_16x32": info["wide_blocks"],
-                   "waves_per_window": info["waves_per_window"], "parallelism": "1 GPU"},
+                   "waves_per_window": info["waves_per_window"], "lds_column_ranges": info.get("lds_ranges", 0), "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": load_traffic(kname.split("<")[0], "%s_d%d" % (args.shape, D)),

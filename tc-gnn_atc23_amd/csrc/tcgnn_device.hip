@@ -1487,6 +1487,7 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
     return hipGetLastError();
 }
 
+static int g_lds_auto = [] { const char* e = getenv("TCGNN_LDS_AUTO"); return e ? atoi(e) : 1; }();
 static int g_lds_dbg = [] { const char* e = getenv("TCGNN_LDS_DBG"); return e ? atoi(e) : 0; }();
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1516,7 +1517,7 @@ static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std:
 // enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
-                          const _Float16** x16_out, int* dpad_out, int* pitch_out) {
+                          const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false) {
     const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
@@ -1537,7 +1538,10 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
-    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
+    if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
+        if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr);
+        else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr);
+    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
     else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
@@ -1608,27 +1612,29 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return TCGNN_OK;
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
+    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges
+    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_nranges > 0));
+    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
+    if (lds) {
+        if (plan->lds_nranges == 0) {   // forced on a plan built without the cell stream (tests, tools): build it now
+            const int brc = build_lds_cells(const_cast<tcgnn_plan*>(plan), stream);
+            if (brc) return brc;
+        }
+        SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1,
+                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg};
+        const int lfull = dpad / kLdsChunkDims, lrem = (dpad % kLdsChunkDims) / 16;
+        KernelTimer timer(plan, stream);
+        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(4, l, lfull, stream)); }
+        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(lrem, l, 1, stream)); }
+        return TCGNN_OK;
+    }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges
-    if (!d_val && (mode == 3 || (mode == 0 && plan->lds_nranges > 0))) {
-        if (mode == 3 && plan->lds_nranges == 0) {   // forced on a plan built without the cell stream (tests, tools): build it now
-            const int brc = build_lds_cells(const_cast<tcgnn_plan*>(plan), stream);
-            if (brc) return brc;
-        }
-        SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, pitch, 0, plan->Nc + 1,
-                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg};
-        const int lfull = dpad / kLdsChunkDims, lrem = (dpad % kLdsChunkDims) / 16;
-        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(4, l, lfull, stream)); }
-        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(lrem, l, 1, stream)); }
-        return TCGNN_OK;
-    }
     const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || x16_bytes > kBlockedMinBytes);
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
@@ -1836,6 +1842,17 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
             }
             if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "bucket table: %s", hipGetErrorString(e)));
             p->bytes += b_bp;
+        }
+    }
+    // Cell stream of the LDS-resident column-range SpMM, for graphs dense enough that a feature row streamed into a
+    // CU's LDS is used more than once by the 64 windows resident there (Reddit: 2.2 uses; ogbn-products: 0.02) and
+    // big enough that the gather walks would leave the L2 (tcgnn_lds_spmm.inc).  TCGNN_LDS_AUTO=0 disables it.
+    if (g_lds_auto && nw >= 4 * p->num_cus && (size_t)num_cols * 128 >= kBlockedMinBytes) {
+        const double uses = (double)num_edges * (kLdsWaves * kLdsMaxW * kWinRows) / ((double)std::max(num_rows, 1) * (double)std::max(num_cols, 1));
+        const double cells = (double)nw * ((double)num_cols / kLdsRows + 1.0);
+        if (uses >= 1.5 && cells < 1.0e9) {
+            const int rc = build_lds_cells(p, stream);
+            if (rc) return bail(rc);
         }
     }
     *plan_out = p;

@@ -471,6 +471,18 @@ def test_full_size_reddit_shape_properties(dev, T):
     g = torch.Generator(device=dev).manual_seed(0)
     X1 = torch.randn(n, 64, device=dev, generator=g); X2 = torch.randn(n, 64, device=dev, generator=g)
     Y1 = T.forward(X1, *meta)[0]; Y2 = T.forward(X2, *meta)[0]; Y12 = T.forward(X1 + 2 * X2, *meta)[0]
+    # this graph is dense enough for the LDS-resident column-range kernel (the automatic choice above): the range-blocked
+    # gather walk and the per-window walk must give the same sums (fp32 accumulation order differs: ~1e-5 of the scale)
+    import tcgnn_capi as c
+    assert T.plan_info(*meta)["lds_ranges"] == (n + 503) // 504
+    try:
+        for mode in (1, 2):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            Ym = T.forward(X1, *meta)[0]
+            assert ((Ym - Y1).abs() / (deg.sqrt()[:, None] + 1)).max().item() < 1e-4, mode
+            assert torch.equal(T.forward(ones, *meta)[0], Yd)
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
     scale = deg.sqrt()[:, None] * 3 + 1
     assert ((Y12 - (Y1 + 2 * Y2)).abs() / scale).max().item() < 3e-2      # three independently rounded operands
     Yv = T.forward_AGNN(X1, rp, col, torch.ones(1, E, device=dev), bp, e2c, e2r)[0]
