@@ -144,7 +144,8 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * range-blocked when the fp16 image of X exceeds the L2 and the windows are long), 1 = always the
  * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table, 3 = the
  * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
- * plan was created without one).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
+ * plan was created without one), 4 = the single-launch fp32-MFMA kernel small graphs take automatically
+ * (no staging pass; binary SpMM only).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
  * initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
 

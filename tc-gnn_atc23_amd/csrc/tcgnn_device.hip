@@ -1371,6 +1371,62 @@ __global__ void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n
 }
 
 // ------------------------------------------------------------------------------------------
+// Small graphs: SpMM in ONE launch (binary A).
+// Citeseer / Cora / Pubmed-sized inputs are launch-latency work (reference: 0.040 ms per call on an RTX 3090,
+// logs/profile.csv:2): the fp16 path costs a memset + absmax + convert + the kernel.  Here one wavefront per window reads
+// fp32 X directly, rounds each operand to a 10-bit mantissa like the reference's TF32 conversion (round_rna10: no range
+// limit, so no scale pass) and multiplies on the fp32 matrix pipe: v_mfma_f32_16x16x4_f32, A = 16 rows x 4 condensed
+// columns of the adjacency mask as 0.0 / 1.0, B = the 4 gathered rows x 16 feature columns.  1/16 of the fp16 MFMA rate,
+// irrelevant at this size.  Accumulation in tile order, fp32, like the other kernels.
+// ------------------------------------------------------------------------------------------
+struct SpmmSmallArgs {
+    const int64_t* wb_ptr;
+    const int32_t* cols;
+    const uint32_t* mask;
+    const float* x;
+    float* y;
+    int32_t N, Nc, D;
+};
+typedef float floatx4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
+    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+    const int w = blockIdx.x;
+    const int coloff = (int)blockIdx.y * 64;
+    floatx4s acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = floatx4s{0.f, 0.f, 0.f, 0.f};
+    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+    for (int64_t t = tb; t < te; ++t) {
+        const uint32_t m = a.mask[t * kWinRows + i];
+        int32_t id[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) id[j] = a.cols[t * kWbCols + 4 * j + g];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float av = ((m >> (4 * j + g)) & 1u) ? 1.0f : 0.0f;
+            const float* row = a.x + (int64_t)id[j] * a.D + coloff + i;
+            const bool live = id[j] < a.Nc;   // Nc = "no column": the zero sentinel of the packed stream
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float bv = (live && coloff + 16 * s + i < a.D) ? round_rna10(row[16 * s]) : 0.0f;
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s], 0, 0, 0);
+            }
+        }
+    }
+    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int colg = coloff + 16 * s + i;
+        if (colg < a.D) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii];
+        }
+    }
+}
+static constexpr int64_t kSmallMaxTiles = 8192;   // wide blocks up to which the single-launch kernel is used (mode 0)
+
+// ------------------------------------------------------------------------------------------
 // fallbacks for non-canonical CSR rows (unsorted or duplicated column ids)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __restrict__ rowptr,
@@ -1611,8 +1667,15 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     }
+    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
+    if (!d_val && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
+        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_Y, plan->N, plan->Nc, D};
+        KernelTimer timer(plan, stream);
+        hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
+        HIP_TRY(hipGetLastError());
+        return TCGNN_OK;
+    }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges
     const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_nranges > 0));
     int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds);
     if (rc) return rc;
@@ -1877,7 +1940,7 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
 }
 
 int tcgnn_set_spmm_mode(int32_t mode) {
-    if (mode < 0 || mode > 3) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked) or 3 (LDS-resident ranges)");
+    if (mode < 0 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked), 3 (LDS-resident ranges) or 4 (single-launch fp32 kernel)");
     g_spmm_mode = mode;
     return TCGNN_OK;
 }

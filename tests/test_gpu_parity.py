@@ -92,7 +92,17 @@ def test_three_kernels_match_oracle(dev, T, case, D):
     Y = T.forward(tX, trp, tcol, tbp, te2c, te2r)
     assert isinstance(Y, list) and len(Y) == 1 and Y[0].shape == (n, D) and Y[0].dtype == torch.float32
     Y64, absY = O.spmm_f64(X, rp, col)
-    assert_parity(Y[0].cpu().numpy(), O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32), Y64, absY, "spmm", unit)
+    Yref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(Y[0].cpu().numpy(), Yref, Y64, absY, "spmm", unit)
+    # small graphs take the single-launch fp32-MFMA kernel automatically: both it and the fp16 per-window kernel are
+    # checked on every case (mode 4 / mode 1), whatever the automatic choice was
+    import tcgnn_capi as c
+    try:
+        for mode in (1, 4):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            assert_parity(T.forward(tX, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy(), Yref, Y64, absY, "spmm mode %d" % mode, unit)
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
 
     Yv = T.forward_AGNN(tX, trp, tcol, tatt.view(1, -1), tbp, te2c, te2r)[0]
     Yv64, absYv = O.spmm_f64(X, rp, col, att)
