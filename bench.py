@@ -200,6 +200,28 @@ def single_gpu(args):
             extra["sddmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward_ef(X2, *meta), sddmm_bytes(n, E, d2), reps=10)
             del X2
         del att
+        # ---- the same SpMM on a degree-skewed graph of the same size (real Reddit: max degree 21 657 at a mean of 492;
+        #      skew 0.6 gives a ~24 k hub): heavy windows must not stall the persistent walks
+        try:
+            rp_s, col_s = G.synthetic_csr(n, nnz_target, seed=args.seed + 1, device=dev, skew=0.6)
+            Es = col_s.numel()
+            bp_s = torch.zeros(nw, dtype=torch.int32, device=dev); e2c_s = torch.zeros(Es, dtype=torch.int32, device=dev); e2r_s = torch.zeros(Es, dtype=torch.int32, device=dev)
+            devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); sys.stdout.flush(); os.dup2(devnull, 1)
+            try:
+                TCGNN.preprocess_gpu(col_s, rp_s, n, 16, 8, bp_s, e2c_s, e2r_s)
+            finally:
+                sys.stdout.flush(); os.dup2(saved, 1); os.close(saved); os.close(devnull)
+            meta_s = (rp_s, col_s, bp_s, e2c_s, e2r_s)
+            for _ in range(3):
+                TCGNN.forward(X, *meta_s)
+            TCGNN.kernel_timing(*meta_s, max_calls=10)
+            el = sync_time(lambda: TCGNN.forward(X, *meta_s), 10, 0, noop)
+            km = TCGNN.kernel_timing(*meta_s); TCGNN.kernel_timing(*meta_s, max_calls=0)
+            extra["spmm_d%d_skewed_graph" % D] = {"gteps": round(Es / (el / 10) / 1e9, 3), "kernel_ms": round(float(np.mean(km)), 4),
+                                                  "max_degree": int((rp_s[1:] - rp_s[:-1]).max()), "nnz": int(Es)}
+            del rp_s, col_s, bp_s, e2c_s, e2r_s, meta_s
+        except Exception as exc:   # the extra leg must never take the headline down
+            extra["spmm_d%d_skewed_graph" % D] = {"error": str(exc)[:200]}
         # ---- end-to-end epochs (main_tcgnn.py:146-181): 2 layers, hidden = D, 9 warm-up epochs
         feats = torch.randn(n, in_dim, device=dev, generator=g)
         labels = torch.ones(n, dtype=torch.long, device=dev)

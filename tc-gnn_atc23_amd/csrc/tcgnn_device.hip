@@ -57,7 +57,7 @@ struct tcgnn_plan {
     int32_t N = 0, nw = 0, nw_eff = 0;   // N: rows of A (= rows of Y)
     int32_t Nc = 0;                      // columns of A = rows of X (== N unless row-sharded)
     int32_t row_off = 0;                 // X row holding A's row 0 (row-sharded SDDMM)
-    int64_t E = 0, tc_blocks = 0, total_wb = 0;
+    int64_t E = 0, tc_blocks = 0, total_wb = 0, max_wb = 0;   // max_wb: wide blocks of the longest window
     int canonical = 0, waves = 1;
     const int32_t *rowptr = nullptr, *col = nullptr, *bp = nullptr, *e2c = nullptr, *e2r = nullptr; // borrowed
     int64_t* d_wb_ptr = nullptr;  // [nw_eff + 1] first wide block of each window
@@ -1571,6 +1571,14 @@ static size_t workspace_bytes_for(int32_t N, int32_t D) {
 static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std::max(plan->nw_eff, 1) * sizeof(double)) + 255) / 256 * 256; }
 
 // enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
+// The range-blocked walks bind up to 4 windows to one persistent wavefront for the whole launch: a hub window (skewed
+// degrees) then holds its wavefront far beyond the others (measured on a Reddit-sized graph with a 93 k-degree hub:
+// 2.48 ms against 1.60 ms for the per-window walk, which spreads a window over 4 wavefronts).  Automatic mode only takes
+// them when the longest window is within 8x the mean.
+static bool windows_balanced(const tcgnn_plan* plan) {
+    return plan->nw_eff > 0 && plan->max_wb * (int64_t)plan->nw_eff <= 8 * std::max<int64_t>(plan->total_wb, 1);
+}
+
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
                           const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false) {
@@ -1698,7 +1706,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || x16_bytes > kBlockedMinBytes);
+    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan)));
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
         if (const char* e = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // tuning experiments only
@@ -1849,6 +1857,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         if (bp[(size_t)w] < 0) return bail(fail(TCGNN_ERR_BAD_GRAPH, "blockPartition[%d] = %d is negative", w, bp[(size_t)w]));
         p->tc_blocks += bp[(size_t)w];
         wb_ptr[(size_t)w + 1] = wb_ptr[(size_t)w] + (bp[(size_t)w] + 3) / 4;
+        p->max_wb = std::max<int64_t>(p->max_wb, (bp[(size_t)w] + 3) / 4);
     }
     p->total_wb = wb_ptr[(size_t)nw];
     std::vector<int32_t> order((size_t)std::max(nw, 1));
@@ -2006,7 +2015,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
-    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || x16_bytes > kBlockedMinBytes);
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan)));
     hipError_t e;
     if (blocked) {
         size_t range_bytes = 4 * kRangeTargetBytes;

@@ -11,7 +11,8 @@ import TCGNN, tcgnn_graph as G, tcgnn_capi as c
 dev = torch.device("cuda:0")
 shape = sys.argv[1] if len(sys.argv) > 1 else "reddit"
 n, nnz, _, _ = G.SHAPES[shape]
-rp, col = G.synthetic_csr(n, nnz, seed=0, device=dev)
+skew = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # > 0: skewed degrees (heavy windows)
+rp, col = G.synthetic_csr(n, nnz, seed=0, device=dev, skew=skew)
 E = col.numel(); nw = (n + 15) // 16
 bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
 TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
@@ -19,7 +20,9 @@ meta = (rp, col, bp, e2c, e2r)
 print(TCGNN.plan_info(*meta))
 g = torch.Generator(device=dev).manual_seed(0)
 att = torch.randn(1, E, device=dev, generator=g)
-for D in (64, 16, 32, 128, 41):
+deg = (rp[1:] - rp[:-1])
+print("skew %.1f: max degree %d, mean %.1f" % (skew, int(deg.max()), float(deg.float().mean())))
+for D in ((64, 16, 32, 128, 41) if len(sys.argv) <= 3 else tuple(int(x) for x in sys.argv[3].split(","))):
     X = torch.randn(n, D, device=dev, generator=g)
     res = {}
     for name, fn in (("spmm", lambda: TCGNN.forward(X, *meta)[0]), ("spmm_val", lambda: TCGNN.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0])):
