@@ -287,6 +287,10 @@ def multi_gpu(args):
                        local=(lrp.cpu().numpy().astype(np.int32), cols.cpu().numpy()))
     del rows, cols, keys
     x_local = torch.randn(n0, D, device=dev, generator=g)
+    import tcgnn_capi as _c
+    _info = _c.PlanInfo()
+    _c.check(_c.lib.tcgnn_plan_get_info(shard.ops.plan, _c.ctypes.byref(_info)), "tcgnn_plan_get_info")
+    shard_kernel = "spmm_lds_kernel" if _info.lds_ranges > 0 else ("spmm_blocked_kernel / spmm_kernel" if _info.column_buckets > 0 else "spmm_kernel")
     # North star: "an RCCL all-reduce of the dense feature-update only where the graph is too large for one
     # 288 GB HBM".  When the global X fits one GPU it is replicated (gathered once, outside the timed region)
     # and a step is the local SpMM on this rank's row windows; otherwise every step all-gathers X.
@@ -305,7 +309,22 @@ def multi_gpu(args):
     t_other = sync_time(other, max(3, args.steps // 5), 2, barrier) * args.steps / max(3, args.steps // 5)
     t_nox = t_other if exchange else elapsed
     t_withx = elapsed if exchange else t_other
-    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx], dtype=torch.float64, device=dev)
+    # ---- one sharded GCN training epoch (2 layers, hidden D, main_tcgnn.py:146-181 on the shard): X W locally, all-gather +
+    #      local SpMM forward and backward in both layers, one all-reduce of the weight gradients
+    gcn_ms = float("nan")
+    try:
+        _, _, in_dim, classes = G.SHAPES[args.shape]
+        feats = torch.randn(n0, in_dim, device=dev, generator=g)
+        labels = torch.ones(n0, dtype=torch.long, device=dev)
+        model = S.ShardedGCN(in_dim, D, classes, num_layers=2, seed=args.seed).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        ep = lambda: S.sharded_train_step(model, shard, feats, labels, opt, n_global)
+        gcn_ms = sync_time(ep, max(2, args.epochs // 2), 3, barrier) * 1e3 / max(2, args.epochs // 2)
+        del feats, model, opt
+    except Exception as exc:   # the extra leg must never take the headline down
+        if rank == 0:
+            print("sharded GCN leg failed: %s" % str(exc)[:300], file=sys.stderr)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms], dtype=torch.float64, device=dev)
     mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     out = None
@@ -322,13 +341,14 @@ def multi_gpu(args):
             "config": {"workload": "row-sharded %s-shape graph: %d nodes total, %d rows and ~%d nnz per GPU, SpMM D=%d, %s"
                                    % (args.shape, n_global, n0, E_local, D, "X all-gathered every step" if exchange else "X replicated (fits one GPU), no collective in the step"),
                        "parallelism": "row-window sharding x%d%s" % (world, ", RCCL all_gather_into_tensor of X" if exchange else "")},
-            "roofline": {"bound": "hbm", "kernel": "spmm_kernel (slowest rank)", "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "%s (slowest rank)" % shard_kernel, "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5), "traffic": None, "algorithmic_bytes": roof_b,
                          "kernel_ms_mean": round(k_mean, 4)},
             "extra": {"exchange_in_timed_step": exchange, "ms_per_step_without_exchange": round(t_local * 1e3 / args.steps, 4),
                       "ms_per_step_with_exchange": round(t_x * 1e3 / args.steps, 4),
                       "exchange_fraction_if_exchanged": round(max(0.0, 1.0 - t_local / t_x), 4),
-                      "gathered_X_bytes": int(shard.layout.num_cols) * D * 4},
+                      "gathered_X_bytes": int(shard.layout.num_cols) * D * 4,
+                      "gcn_ms_per_epoch_sharded": None if np.isnan(float(mx[5])) else round(float(mx[5]), 3)},
         }
     dist.barrier()
     dist.destroy_process_group()

@@ -240,3 +240,45 @@ def allreduce_gradients(params, group=None):
     for g in grads:
         g.copy_(flat[off: off + g.numel()].view_as(g))
         off += g.numel()
+
+
+class ShardedGCN(torch.nn.Module):
+    """The harness's GCN (tcgnn_harness.Net with GCNConv = main_tcgnn.py:75-139: conv1 -> relu -> dropout -> ... -> conv2 ->
+    log_softmax) on a row-sharded graph.  Every rank holds its rows of the features and labels and a full copy of the
+    (KB-sized) weights; a layer is the local dense update X_local W followed by `shard.aggregate` (one all-gather of the
+    N x D update + the local SpMM); the backward pass of the aggregation is the same exchange on dY (A, not A^T: the
+    reference's symmetric-graph convention).  Nothing else crosses the fabric until the weight gradients are summed."""
+
+    def __init__(self, in_dim, hidden, classes, num_layers=2, dropout=0.5, seed=0):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)   # identical initial weights on every rank
+        dims = [in_dim] + [hidden] * (num_layers - 1) + [classes]
+        self.weights = torch.nn.ParameterList(torch.nn.Parameter(torch.randn(a, b, generator=gen)) for a, b in zip(dims[:-1], dims[1:]))
+        self.dropout = dropout
+
+    def forward(self, x_local, shard):
+        h = x_local
+        last = len(self.weights) - 1
+        for k, w in enumerate(self.weights):
+            h = shard.aggregate(torch.mm(h, w))
+            if k != last:
+                h = torch.relu(h)
+                if k == 0 and self.dropout > 0:
+                    h = torch.nn.functional.dropout(h, p=self.dropout, training=self.training)
+        return torch.log_softmax(h, dim=1)
+
+
+def sharded_train_step(model, shard, x_local, y_local, optimizer, num_nodes_global):
+    """One epoch of main_tcgnn.py:146-152 on the shard: nll_loss is the mean over ALL nodes, so every rank back-propagates
+    its local sum / N and the weight gradients are summed with one all-reduce.  Returns the global loss."""
+    model.train()
+    optimizer.zero_grad()
+    logp = model(x_local, shard)
+    loss_local = -logp.gather(1, y_local.view(-1, 1)).sum() / float(num_nodes_global)
+    loss_local.backward()
+    allreduce_gradients(list(model.parameters()), shard.group)
+    optimizer.step()
+    loss = loss_local.detach().clone()
+    if dist.is_initialized() and dist.get_world_size(shard.group) > 1:
+        dist.all_reduce(loss, group=shard.group)
+    return loss

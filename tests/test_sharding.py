@@ -118,3 +118,54 @@ def test_two_rank_sharded_aggregation_matches_single_process(tmp_path):
     for r in range(2):
         flags = np.load(os.path.join(tmp_path, "rank%d.npy" % r))
         assert flags.all(), open(os.path.join(tmp_path, "rank%d.txt" % r)).read()
+
+
+def _gcn_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tc-gnn_atc23_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rp, col = graphs.powerlaw_graph(500, 12, seed=9)          # symmetric
+        n, in_dim, hidden, classes = 500, 20, 16, 5
+        rng = np.random.default_rng(1)
+        X = (rng.standard_normal((n, in_dim)) * 0.1).astype(np.float32)
+        y = rng.integers(0, classes, size=n)
+        shard = S.RowShard(rp, col, ops_factory=OracleShardOps)
+        b0, b1 = shard.layout.bounds[rank], shard.layout.bounds[rank + 1]
+        model = S.ShardedGCN(in_dim, hidden, classes, num_layers=2, dropout=0.0, seed=3)
+        model.weights[0].data.mul_(0.1); model.weights[1].data.mul_(0.1)
+        w0 = [w.detach().clone() for w in model.weights]
+        opt = torch.optim.SGD(model.parameters(), lr=0.5)
+        loss = S.sharded_train_step(model, shard, torch.from_numpy(X[b0:b1]), torch.from_numpy(y[b0:b1]), opt, n)
+        # the same step on the whole graph in one process, dense A, autograd
+        A = np.zeros((n, n), np.float32)
+        for r in range(n):
+            A[r, col[rp[r]:rp[r + 1]]] = 1.0
+        At = torch.from_numpy(A)
+        W = [w.clone().requires_grad_(True) for w in w0]
+        h = torch.relu(At @ (torch.from_numpy(X) @ W[0]))
+        logp = torch.log_softmax(At @ (h @ W[1]), dim=1)
+        ref_loss = -logp.gather(1, torch.from_numpy(y).view(-1, 1)).mean()
+        ref_loss.backward()
+        ok = {"loss": abs(float(loss) - float(ref_loss)) < 1e-5 * max(1.0, abs(float(ref_loss)))}
+        for k in range(2):
+            ok["w%d" % k] = torch.allclose(model.weights[k].detach(), w0[k] - 0.5 * W[k].grad, rtol=1e-4, atol=1e-6)
+        np.save(os.path.join(out_dir, "gcn_rank%d.npy" % rank), np.array([int(v) for v in ok.values()]))
+        with open(os.path.join(out_dir, "gcn_rank%d.txt" % rank), "w") as f:
+            f.write(repr(ok) + " loss %.6f ref %.6f" % (float(loss), float(ref_loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_gcn_step_equals_single_process_step(tmp_path):
+    """Forward loss and the SGD-updated weights of one sharded training step (all-gather in both directions of both
+    layers, summed weight gradients) equal the same step taken on the whole graph in one process."""
+    port = _free_port()
+    mp.spawn(_gcn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        flags = np.load(os.path.join(tmp_path, "gcn_rank%d.npy" % r))
+        assert flags.all(), open(os.path.join(tmp_path, "gcn_rank%d.txt" % r)).read()
