@@ -71,7 +71,7 @@ struct tcgnn_plan {
     int32_t num_cus = 256;
     size_t bytes = 0;
     // cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc); lds_nranges == 0: not built
-    int32_t lds_nranges = 0, lds_nwg = 0;
+    int32_t lds_nranges = 0, lds_nwg = 0, lds_maxw = 0;   // lds_maxw: windows per wavefront the stream was laid out for (4 or 8)
     int64_t lds_tiles = 0;
     uint32_t* d_cell_ptr = nullptr;    // [lds_nwg * lds_nranges * 64 + 1] tile offset of cell (workgroup, range, wavefront, window slot)
     uint32_t* d_cell_tiles = nullptr;  // [lds_tiles][32] 32 u16 row ids local to the range + 16 mask words
@@ -1614,6 +1614,7 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 
 // Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
 // condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
+static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); return (e && atoi(e) == 8) ? kLdsMaxW2 : kLdsMaxW; }();
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
@@ -1621,9 +1622,12 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     const int nw = p->nw_eff;
     if (nw <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
     const int nranges = (p->Nc + kLdsRows - 1) / kLdsRows;
-    const int per_wg = kLdsWaves * kLdsMaxW;
+    const int maxw = g_lds_maxw;
+    const int per_wg = kLdsWaves * maxw;
     int nwg = (nw + per_wg - 1) / per_wg;
-    if (nwg < p->num_cus) nwg = std::max(nwg, std::min(p->num_cus, (nw + kLdsWaves - 1) / kLdsWaves));   // spread over every CU
+    // spread over every CU; with 8 windows per wavefront a 64-column matrix takes two passes (grid.y), hence half the CUs per pass
+    const int cu_target = maxw == kLdsMaxW2 ? std::max(1, p->num_cus / 2) : p->num_cus;
+    if (nwg < cu_target) nwg = std::max(nwg, std::min(cu_target, (nw + kLdsWaves - 1) / kLdsWaves));
     const int64_t ncell = (int64_t)nwg * nranges * per_wg;
     uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
     auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); return rc; };
@@ -1633,7 +1637,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     const int64_t nthreads = (int64_t)nw * nranges;
     hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, nw, nwg,
-                       nranges, p->Nc, d_cnt, d_firstq);
+                       nranges, p->Nc, maxw, d_cnt, d_firstq);
     std::vector<uint32_t> cnt((size_t)ncell + 1);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -1649,14 +1653,14 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
     hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords);
     hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       d_cnt, d_firstq, d_tiles);
+                       maxw, d_cnt, d_firstq, d_tiles);
     if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `cnt` must outlive its copy
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
     (void)hipFree(d_firstq);
     p->d_cell_ptr = d_cnt; p->d_cell_tiles = d_tiles;
-    p->lds_nwg = nwg; p->lds_tiles = ntiles;
+    p->lds_nwg = nwg; p->lds_tiles = ntiles; p->lds_maxw = maxw;
     p->bytes += (size_t)(ncell + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t);
     p->lds_nranges = nranges;
     return TCGNN_OK;
@@ -1695,10 +1699,11 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1,
                       plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg};
-        const int lfull = dpad / kLdsChunkDims, lrem = (dpad % kLdsChunkDims) / 16;
+        const int cdims = lds_chunk_dims(plan->lds_maxw);
+        const int lfull = dpad / cdims, lrem = (dpad % cdims) / 16;
         KernelTimer timer(plan, stream);
-        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(4, l, lfull, stream)); }
-        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(lrem, l, 1, stream)); }
+        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(plan->lds_maxw, cdims / 16, l, lfull, stream)); }
+        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(plan->lds_maxw, lrem, l, 1, stream)); }
         return TCGNN_OK;
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1};

@@ -7,6 +7,7 @@ accumulate).  Because the staging pass rounds exactly like cvt.rna.tf32, the mea
 accumulation-order noise only, so a second, much tighter bound relative to sum|a||x| is asserted too.
 """
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -316,6 +317,18 @@ def test_lds_resident_range_kernel_matches_oracle_and_plain_walk(dev, T, D, shap
     ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
     for mode in (1, 3):
         assert_parity(out[mode], ref, Y64, absY, "spmm mode %d" % mode)
+
+def test_lds_resident_range_kernel_with_eight_windows_per_wavefront():
+    """The alternative layout of the LDS-resident kernel (TCGNN_LDS_MAXW=8: 8 windows per wavefront, 32 feature columns
+    per pass; measured slower on Reddit, kept selectable) is read from the environment when the library loads, so the
+    parity test above is re-run in a child process with the variable set."""
+    env = dict(os.environ, TCGNN_LDS_MAXW="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_lds_resident_range_kernel_matches_oracle_and_plain_walk and (64 or 41 or 160)"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
 
 @pytest.mark.parametrize("D", [16, 64, 41, 128])
 def test_fused_agnn_range_major_walk_equals_per_window_walk(dev, T, D):
