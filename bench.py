@@ -128,7 +128,9 @@ def single_gpu(args):
         sys.stdout.flush(); os.dup2(saved, 1); os.close(saved); os.close(devnull)
     sgt_equal = bool(torch.equal(bp.cpu(), bp_h) and torch.equal(e2c.cpu(), e2c_h) and torch.equal(e2r.cpu(), e2r_h))
     meta = (rp_d, col_d, bp, e2c, e2r)
-    info = TCGNN.plan_info(*meta)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    info = TCGNN.plan_info(*meta)   # first sight of the five arrays: packs the tile stream (+ the cell stream of dense graphs)
+    torch.cuda.synchronize(); plan_ms = (time.perf_counter() - t0) * 1e3
 
     g = torch.Generator(device=dev).manual_seed(args.seed)
     X = torch.randn(n, D, device=dev, generator=g)
@@ -170,7 +172,7 @@ def single_gpu(args):
                      "kernel_launches_timed": len(kernel_ms)},
     }
     extra = {"graph_gen_s": round(gen_s, 2), "host_sgt_ms": round(host_sgt_ms, 1), "host_sgt_ns_per_edge": round(host_sgt_ms * 1e6 / E, 2),
-             "device_sgt_ms": round(dev_sgt_ms, 1), "device_sgt_equals_host_sgt": sgt_equal, "plan_bytes": info["plan_bytes"],
+             "device_sgt_ms": round(dev_sgt_ms, 1), "device_sgt_equals_host_sgt": sgt_equal, "plan_create_ms": round(plan_ms, 1), "plan_bytes": info["plan_bytes"],
              "staging_plus_launch_ms_per_step": round(ms_per_step - k_mean, 4)}
 
     if not args.no_extra:
@@ -229,6 +231,11 @@ def single_gpu(args):
             r = H.time_training(model, meta, feats, labels, in_dim, D, classes, 2, args.epochs, seed=args.seed)
             extra["%s_ms_per_epoch" % model] = round(r["train_ms"], 3)
             extra["%s_final_loss_finite" % model] = bool(np.isfinite(r["final_loss"]))
+            try:   # the same epoch captured once in a HIP graph and replayed (tcgnn_harness --hip_graph)
+                rg = H.time_training(model, meta, feats, labels, in_dim, D, classes, 2, args.epochs, seed=args.seed, warmup=3, hip_graph=True)
+                extra["%s_ms_per_epoch_hip_graph" % model] = round(rg["train_ms"], 3)
+            except Exception as exc:
+                extra["%s_ms_per_epoch_hip_graph" % model] = "failed: %s" % str(exc)[:120]
         del feats
 
     if not args.no_cpu:

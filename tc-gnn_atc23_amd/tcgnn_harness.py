@@ -36,6 +36,7 @@ def build_parser():
     p.add_argument("--graph_dir", type=str, default="tcgnn-ae-graphs/")
     p.add_argument("--gpu_preprocess", action="store_true", help="run the sparse-graph translation on the GPU")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--hip_graph", action="store_true", help="capture one epoch in a HIP graph after the dry epochs and replay it (not in the reference)")
     return p
 
 
@@ -81,9 +82,12 @@ def node_nll_loss(log_probs, y):
     return -log_probs.gather(1, y.view(-1, 1)).mean()
 
 
-def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9):
+def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9, hip_graph=False):
     """The timed part of main_tcgnn.py (:141-181) on tensors that already live on the GPU:
-    Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones."""
+    Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones.
+    hip_graph: capture one whole epoch (forward, loss, backward, Adam step - the reference already asks for a capturable
+    Adam, main_tcgnn.py:143) in a HIP graph after the dry epochs and replay it: on Citeseer-sized graphs an epoch is
+    ~60 launches of a few microseconds each and the host, not the GPU, sets the time."""
     import tcgnn_layers as L
     conv_cls = {"gcn": L.GCNConv, "gin": L.GINConv, "agnn": L.AGNNConv}[model_name]
     torch.manual_seed(seed)
@@ -101,6 +105,27 @@ def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, e
     for _ in range(warmup):
         train()
     torch.cuda.synchronize()
+    if hip_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # allocator / workspace warm-up on a side stream, as graph capture requires
+            for _ in range(3):
+                train()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        model.train()
+        with torch.cuda.graph(graph):
+            static_loss = node_nll_loss(model(x, meta), y)
+            static_loss.backward()
+            optimizer.step()
+        graph.replay()
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in range(epochs):
+            graph.replay()
+        torch.cuda.synchronize()
+        return {"train_ms": (time.perf_counter() - start) * 1e3 / max(epochs, 1), "final_loss": float(static_loss.detach()), "hip_graph": True}
     start = time.perf_counter()
     for _ in range(epochs):
         loss = train()
@@ -144,7 +169,7 @@ def run(args, quiet=False):
         return result
 
     r = time_training(args.model, meta, x, y, ds.num_features, args.hidden, ds.num_classes, args.num_layers, args.epochs,
-                      seed=args.seed, warmup=9)  # 9 dry epochs, main_tcgnn.py:166-167
+                      seed=args.seed, warmup=9, hip_graph=getattr(args, "hip_graph", False))  # 9 dry epochs, main_tcgnn.py:166-167
     say("Train (ms):\t{:6.3f}".format(r["train_ms"]))
     result.update(r)
     return result

@@ -411,6 +411,27 @@ def test_agnn_layer_gives_the_same_gradients_fused_and_separate(dev, T):
         assert got.shape == want.shape and float((got - want).abs().max()) <= tol * scale, what
 
 
+def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
+    """tcgnn_harness.time_training(hip_graph=True) captures forward + loss + backward + Adam step once and replays it: every
+    kernel of the path must be capturable (no allocation outside torch's pool, no synchronisation, current-stream launches)
+    and the replayed epochs must keep training (labels are all ones: the loss falls as in the eager loop)."""
+    import tcgnn_harness as H
+    rp, col = graphs.uniform_graph(3327, 2.8, seed=1)
+    _, (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    n = len(rp) - 1
+    x = torch.randn(n, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    y = torch.ones(n, dtype=torch.long, device=dev)
+    for model in ("gcn", "agnn"):
+        short = H.time_training(model, meta, x, y, 32, 16, 6, 2, epochs=1, seed=0, warmup=2, hip_graph=True)
+        long_g = H.time_training(model, meta, x, y, 32, 16, 6, 2, epochs=40, seed=0, warmup=2, hip_graph=True)
+        long_e = H.time_training(model, meta, x, y, 32, 16, 6, 2, epochs=44, seed=0, warmup=2, hip_graph=False)
+        assert long_g.get("hip_graph") and np.isfinite(long_g["final_loss"]) and np.isfinite(long_e["final_loss"])
+        assert long_g["final_loss"] < short["final_loss"], (model, short, long_g)
+        # same number of optimiser steps; dropout draws differ between the two loops, so the bar is loose
+        assert abs(long_g["final_loss"] - long_e["final_loss"]) <= 0.5 * max(long_e["final_loss"], short["final_loss"]), (model, long_g, long_e)
+
+
 def test_range_robustness_beyond_fp16(dev, T):
     """Values far outside fp16's range (the reference's TF32 has fp32's exponent) survive the
     per-call power-of-two scaling."""
