@@ -262,9 +262,28 @@ def cpu_baseline(rp, col, n, E, D, seed):
             cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
     except (OSError, IndexError):
         pass
-    return {"value": round(E / mean / 1e9, 4), "unit": "GTEPS (SpMM, edges/s/1e9)", "cores": threads, "kind": "port",
-            "sample": "full %d-edge graph, D=%d, %d timed passes after 1 warm-up (mean %.3f s, min %.3f s)" % (E, D, reps, mean, best),
-            "what": "oracle_csr_spmm: row-parallel CSR gather-add, OpenMP, fp32 (DGL-CPU-style aggregation)", "cpu_model": cpu}
+    out = {"value": round(E / mean / 1e9, 4), "unit": "GTEPS (SpMM, edges/s/1e9)", "cores": threads, "kind": "port",
+           "sample": "full %d-edge graph, D=%d, %d timed passes after 1 warm-up (mean %.3f s, min %.3f s)" % (E, D, reps, mean, best),
+           "what": "oracle_csr_spmm: row-parallel CSR gather-add, OpenMP, fp32 (DGL-CPU-style aggregation)", "cpu_model": cpu}
+    # ---- the GCN epoch of the reference's DGL baseline (dgl_baseline/gcn.py + train.py) restated on the host cores
+    #      (oracle/dgl_gcn_cpu.py; DGL itself is absent and unpinned): BASELINE.json configs[0] (Cora shape, hidden 16) and the
+    #      headline graph at hidden D.  Bounded: a few epochs each.
+    try:
+        from oracle import dgl_gcn_cpu as B
+        import tcgnn_graph as G
+        cn, cnnz, cdim, ccls = G.SHAPES["cora"]
+        crp, ccol = G.synthetic_csr(cn, cnnz, seed=seed)
+        cx = np.random.default_rng(seed).standard_normal((cn, cdim)).astype(np.float32)
+        r0 = B.time_training(crp.numpy(), ccol.numpy(), cx, np.ones(cn, np.int64), 16, ccls, epochs=50, threads=min(threads, 16), symmetric=True)
+        out["gcn_epoch_ms_cora_shape_h16"] = round(r0["train_ms"], 3)
+        _, _, in_dim, classes = G.SHAPES["reddit"] if n > 100000 else (0, 0, 64, 8)
+        fx = np.random.default_rng(seed + 1).standard_normal((n, in_dim)).astype(np.float32)
+        r1 = B.time_training(rp, col, fx, np.ones(n, np.int64), D, classes, epochs=2, dry_runs=1, threads=threads, symmetric=True)
+        out["gcn_epoch_ms_same_graph_h%d" % D] = round(r1["train_ms"], 1)
+        out["gcn_epoch_note"] = "GraphConv(norm=both)+bias stack, CrossEntropy, Adam(1e-2, wd 5e-4): %d-thread Cora shape over 50 epochs; headline graph over 2 epochs after 1 dry run" % min(threads, 16)
+    except Exception as exc:   # the epoch leg is an extra: the SpMM baseline above stands on its own
+        out["gcn_epoch_note"] = "failed: %s" % str(exc)[:200]
+    return out
 
 
 def multi_gpu(args):
