@@ -171,6 +171,16 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D);
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D,
                void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* f3 - the dense update's element-wise steps fused around the aggregation (the reference runs them as separate torch
+ * kernels: F.relu after the layer, main_tcgnn.py:100-139; its backward mask before gnn_conv.py:80):
+ *   flags & TCGNN_FUSE_RELU : Y = max(A_bin * X, 0)                      (ReLU epilogue in the kernels' stores)
+ *   d_gate != NULL          : X'[r,c] = d_gate[r,c] > 0 ? X[r,c] : 0     (applied while X is staged to fp16: with
+ *                             d_gate = the forward output this is the ReLU backward mask on dY).  [N, D] like X.
+ * Results are bit-identical to max(tcgnn_spmm(X), 0) and tcgnn_spmm(X * (gate > 0)). */
+#define TCGNN_FUSE_RELU 1
+int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_gate, float* d_Y, int32_t D,
+                     int32_t flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Y[N,D] = A_val * X with A_val[r,c] = d_edge_val[e] for CSR edge e = (r,c).
  * Replaces TCGNN.forward_AGNN (TCGNN.cpp:93-118); d_edge_val is row 0 of edgeAttention[H,E]. */
 int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y,

@@ -32,7 +32,8 @@ import torch
 import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
-           "plan_info", "kernel_timing", "clear_plan_cache", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward"]
+           "plan_info", "kernel_timing", "clear_plan_cache", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
+           "forward_fused"]
 
 _PLAN_CACHE_SIZE = 8
 _plans = collections.OrderedDict()  # key -> (handle, tensors kept alive)
@@ -231,6 +232,31 @@ def forward(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRo
         ws, ws_bytes = _workspace(plan, D, dev)
         st = _c.lib.tcgnn_spmm(plan, input.data_ptr(), out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
     _c.check(st, "tcgnn_spmm")
+    return [out]
+
+
+def forward_fused(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, relu=False, gate=None):
+    """Not in the reference module: `forward` with the layer's element-wise steps fused in.
+    relu=True: max(A @ input, 0) - the ReLU the reference applies after the layer (main_tcgnn.py:100-139) runs in the
+    kernel's stores.  gate (same shape as input): A @ (input * (gate > 0)) - with gate = the forward output, the ReLU
+    backward mask is applied to dY while it is staged.  Bit-identical to the unfused compositions."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    if gate is not None:
+        _check_input(gate, "gate")
+        _check_float(gate, "gate")
+        if gate.shape != input.shape or gate.device != input.device:
+            raise RuntimeError("gate must have the shape and device of input")
+    dev = input.device
+    N, D = input.shape
+    out = torch.empty_like(input)
+    if N == 0 or D == 0:
+        return [out]
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_spmm_fused(plan, input.data_ptr(), gate.data_ptr() if gate is not None else None, out.data_ptr(), D,
+                                     1 if relu else 0, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_spmm_fused")
     return [out]
 
 

@@ -102,6 +102,7 @@ __device__ __forceinline__ int scale_exp_from_bits(uint32_t b) {
     int k = 14 - e;
     return k > 126 ? 126 : (k < -126 ? -126 : k);
 }
+__device__ __forceinline__ float relu_if(int on, float v) { return on ? fmaxf(v, 0.0f) : v; }
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
 
 // Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
@@ -246,13 +247,30 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
     }
 }
 
+// absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
+__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out) {
+    uint32_t m = 0;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gsz)
+        if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+
 // One thread per 16-byte output chunk (8 halves).  Rows: N real + 1 all-zero sentinel row that
 // padding columns of the tile stream point at (the reference zero-fills those, :423-424).
 template <bool VEC>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
                                                       int32_t D, int32_t Dpad, int32_t pitch,
                                                       _Float16* __restrict__ X16,
-                                                      const uint32_t* __restrict__ hdr) {
+                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr) {
     const int cpr = Dpad >> 3;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = ((int64_t)N + 1) * cpr;
@@ -266,11 +284,15 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
         const float4 a = src[0], b = src[1];
         o[0] = to_half_rna(a.x * s); o[1] = to_half_rna(a.y * s); o[2] = to_half_rna(a.z * s); o[3] = to_half_rna(a.w * s);
         o[4] = to_half_rna(b.x * s); o[5] = to_half_rna(b.y * s); o[6] = to_half_rna(b.z * s); o[7] = to_half_rna(b.w * s);
+        if (G) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(G[row * D + d0 + j] > 0.0f)) o[j] = (_Float16)0.0f;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = d0 + j;
-            o[j] = (row < N && d < D) ? to_half_rna(X[row * D + d] * s) : (_Float16)0.0f;
+            o[j] = (row < N && d < D && (!G || G[row * D + d] > 0.0f)) ? to_half_rna(X[row * D + d] * s) : (_Float16)0.0f;
         }
     }
     *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
@@ -292,6 +314,7 @@ struct SpmmArgs {
     int32_t N, D, stride, chunk0;
     int64_t E;
     int32_t xrows;   // rows of X16 including the zero sentinel row
+    int32_t relu;    // fused epilogue: Y = max(A X, 0) (binary SpMM only)
 };
 
 // ---- memory pipeline discipline -----------------------------------------------------------------
@@ -595,7 +618,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, v[ii] * inv1 * inv2);
             }
         }
     } else {
@@ -605,7 +628,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii] * inv1 * inv2;
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[s][ii] * inv1 * inv2);
             }
         }
     }
@@ -718,7 +741,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
                 if (colg < a.D) {
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
-                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[j][s][ii] * inv1 * inv2;
+                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[j][s][ii] * inv1 * inv2);
                 }
             }
         }
@@ -1384,8 +1407,9 @@ struct SpmmSmallArgs {
     const int32_t* cols;
     const uint32_t* mask;
     const float* x;
+    const float* gate;   // optional: operand element (r, c) counts only where gate[r, c] > 0 (ReLU backward mask)
     float* y;
-    int32_t N, Nc, D;
+    int32_t N, Nc, D, relu;
 };
 typedef float floatx4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
@@ -1404,11 +1428,13 @@ __global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float av = ((m >> (4 * j + g)) & 1u) ? 1.0f : 0.0f;
-            const float* row = a.x + (int64_t)id[j] * a.D + coloff + i;
+            const int64_t roff = (int64_t)id[j] * a.D + coloff + i;
+            const float* row = a.x + roff;
             const bool live = id[j] < a.Nc;   // Nc = "no column": the zero sentinel of the packed stream
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float bv = (live && coloff + 16 * s + i < a.D) ? round_rna10(row[16 * s]) : 0.0f;
+                float bv = (live && coloff + 16 * s + i < a.D) ? round_rna10(row[16 * s]) : 0.0f;
+                if (a.gate && live && coloff + 16 * s + i < a.D && !(a.gate[roff + 16 * s] > 0.0f)) bv = 0.0f;
                 acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s], 0, 0, 0);
             }
         }
@@ -1420,7 +1446,7 @@ __global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
         if (colg < a.D) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
-                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = acc[s][ii];
+                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[s][ii]);
         }
     }
 }
@@ -1581,7 +1607,7 @@ static bool windows_balanced(const tcgnn_plan* plan) {
 
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
-                          const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false) {
+                          const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr) {
     const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
@@ -1593,7 +1619,8 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int64_t nx = (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
     }
     if (d_val && plan->E > 0) {
         const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
@@ -1603,10 +1630,10 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
-        if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr);
-        else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr);
-    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr);
+        if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
+        else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
+    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
     return TCGNN_OK;
@@ -1667,7 +1694,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
 }
 
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
-                    void* ws, size_t ws_bytes, void* stream_v) {
+                    void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr) {
     if (!plan || D < 1 || (plan->N > 0 && (!d_X || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->N == 0) return TCGNN_OK;
@@ -1681,7 +1708,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
     if (!d_val && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
-        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_Y, plan->N, plan->Nc, D};
+        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu};
         KernelTimer timer(plan, stream);
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
         HIP_TRY(hipGetLastError());
@@ -1689,7 +1716,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_nranges > 0));
-    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds);
+    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
@@ -1698,7 +1725,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (brc) return brc;
         }
         SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1,
-                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg};
+                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg, relu};
         const int cdims = lds_chunk_dims(plan->lds_maxw);
         const int lfull = dpad / cdims, lrem = (dpad % cdims) / 16;
         KernelTimer timer(plan, stream);
@@ -1706,7 +1733,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(plan->lds_maxw, lrem, l, 1, stream)); }
         return TCGNN_OK;
     }
-    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1};
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -1992,6 +2019,12 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
     return run_spmm(plan, d_X, nullptr, d_Y, D, ws, ws_bytes, stream);
+}
+
+int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_gate, float* d_Y, int32_t D, int32_t flags,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (flags & ~TCGNN_FUSE_RELU) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_fused: unknown flag bits 0x%x", flags & ~TCGNN_FUSE_RELU);
+    return run_spmm(plan, d_X, nullptr, d_Y, D, ws, ws_bytes, stream, (flags & TCGNN_FUSE_RELU) ? 1 : 0, d_gate);
 }
 
 int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y, int32_t D,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tcgnn_workspace_bytes": (_sz, [_vp, _i32]),
     "tcgnn_spmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_spmm_val": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "tcgnn_spmm_fused": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "tcgnn_sddmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_agnn_supported": (ctypes.c_int, [_vp, _i32]),
     "tcgnn_agnn_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),

@@ -50,11 +50,18 @@ class Net(nn.Module):
         self.conv2 = conv_cls(hidden, classes)
         self.relu = nn.ReLU()
 
+    def _act(self, conv, x, meta):
+        # GCNConv can run the ReLU inside its aggregation kernel (tcgnn_layers.TCGNNFunction fuse_relu); same values
+        import tcgnn_layers as L
+        if isinstance(conv, L.GCNConv):
+            return conv(x, *meta, fuse_relu=True)
+        return self.relu(conv(x, *meta))
+
     def forward(self, x, meta):
-        x = self.relu(self.conv1(x, *meta))
+        x = self._act(self.conv1, x, meta)
         x = F.dropout(x, training=self.training)
         for conv in self.hidden_layers:
-            x = self.relu(conv(x, *meta))
+            x = self._act(conv, x, meta)
         x = self.conv2(x, *meta)
         return F.log_softmax(x, dim=1)
 

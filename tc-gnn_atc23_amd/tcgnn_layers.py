@@ -80,18 +80,31 @@ class TCGNNFunction(torch.autograd.Function):
     """GCN layer: dense update first, aggregation second."""
 
     @staticmethod
-    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False):
+        """fuse_relu (not in the reference): the ReLU that follows the layer (main_tcgnn.py:100-139) runs in the
+        SpMM kernel's stores, and its backward mask is applied to dY while dY is staged - relu(layer(x)) without the two
+        element-wise passes over N x D.  Same values as F.relu(layer(x)), bit for bit."""
         ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        ctx.fused = bool(fuse_relu) and hasattr(backend(), "forward_fused")
+        if ctx.fused:
+            Y = backend().forward_fused(torch.mm(X, weights), *ctx.meta, relu=True)[0]
+            ctx.save_for_backward(X, weights, Y)
+            return Y
         ctx.save_for_backward(X, weights)
-        return backend().forward(torch.mm(X, weights), *ctx.meta)[0]
+        Y = backend().forward(torch.mm(X, weights), *ctx.meta)[0]
+        return torch.relu(Y) if fuse_relu else Y   # (a backend without the fused entry point: plain composition, autograd off here)
 
     @staticmethod
     def backward(ctx, d_output):
-        X, weights = ctx.saved_tensors
-        g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
+        if ctx.fused:
+            X, weights, Y = ctx.saved_tensors
+            g = backend().forward_fused(d_output.contiguous(), *ctx.meta, gate=Y)[0]
+        else:
+            X, weights = ctx.saved_tensors
+            g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
         # the input features of the first layer need no gradient: skip their N x in_dim product
         d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
-        return (d_input, tall_tn_mm(X, g)) + (None,) * 5
+        return (d_input, tall_tn_mm(X, g)) + (None,) * 6
 
 
 class TCGNNFunction_GIN(torch.autograd.Function):
@@ -204,8 +217,11 @@ class GCNConv(torch.nn.Module):
         bound = 1.0 / math.sqrt(self.weights.size(1))
         self.weights.data.uniform_(-bound, bound)
 
-    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
-        return TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False):
+        if fuse_relu and hasattr(backend(), "forward_fused"):
+            return TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, True)
+        y = TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        return torch.relu(y) if fuse_relu else y
 
 
 class GINConv(torch.nn.Module):

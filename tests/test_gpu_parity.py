@@ -411,6 +411,47 @@ def test_agnn_layer_gives_the_same_gradients_fused_and_separate(dev, T):
         assert got.shape == want.shape and float((got - want).abs().max()) <= tol * scale, what
 
 
+@pytest.mark.parametrize("D", [16, 41, 64, 100])
+def test_fused_relu_epilogue_and_gated_staging_are_bit_identical_to_the_unfused_steps(dev, T, D):
+    """forward_fused(relu=True) == relu(forward(X)) and forward_fused(gate=G) == forward(X * (G > 0)),
+    exactly, on every SpMM walk (per-window fp16, range-blocked, LDS-resident ranges, single-launch fp32)."""
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(16448, 40, seed=31)
+    _, (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    n = len(rp) - 1
+    g = torch.Generator(device=dev).manual_seed(D)
+    X = torch.randn(n, D, device=dev, generator=g)
+    G = torch.randn(n, D, device=dev, generator=g)
+    try:
+        for mode in (1, 2, 3, 4):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            assert torch.equal(T.forward_fused(X, *meta, relu=True)[0], torch.relu(T.forward(X, *meta)[0])), mode
+            assert torch.equal(T.forward_fused(X, *meta, gate=G)[0], T.forward(X * (G > 0), *meta)[0]), mode
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+
+
+def test_gcn_layer_with_fused_relu_gives_the_same_values_and_gradients(dev, T):
+    import tcgnn_layers as L
+    rp, col = graphs.uniform_graph(3000, 30, seed=32)
+    _, (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    torch.manual_seed(5)
+    conv = L.GCNConv(24, 16).to(dev)
+    x0 = torch.randn(3000, 24, device=dev)
+    dy = torch.randn(3000, 16, device=dev)
+    outs = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        conv.weights.grad = None
+        y = conv(x, *meta, fuse_relu=True) if fused else torch.relu(conv(x, *meta))
+        y.backward(dy)
+        outs.append((y.detach(), x.grad.clone(), conv.weights.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
     """tcgnn_harness.time_training(hip_graph=True) captures forward + loss + backward + Adam step once and replays it: every
     kernel of the path must be capturable (no allocation outside torch's pool, no synchronisation, current-stream launches)
