@@ -1931,6 +1931,10 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess) p->num_cus = prop.multiProcessorCount;
         int nb = 8;
         while (nb < 128 && (int64_t)num_cols / nb > 4096) nb <<= 1;
+        // wide column spaces with short windows (a row shard of a multi-GPU graph: Reddit's 243 tiles per window spread over
+        // N x 232 965 columns): fewer, longer buckets rather than no table - without it the shard falls back to the per-window
+        // walk (measured 1.77 ms against 0.87 ms for the unsharded graph)
+        while (nb > 8 && p->total_wb < (int64_t)2 * nb * nw) nb >>= 1;
         if (nw >= 4 * p->num_cus && p->total_wb >= (int64_t)2 * nb * nw) {
             p->nbuckets = nb;
             p->bucket_rows = (int32_t)(((int64_t)num_cols + nb - 1) / nb);
