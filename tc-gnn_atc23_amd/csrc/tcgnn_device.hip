@@ -1569,6 +1569,7 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
     return hipGetLastError();
 }
 
+static int g_bucket_min_tiles = [] { const char* e = getenv("TCGNN_BUCKET_MIN_TILES"); return e ? atoi(e) : 2; }();   // tiles per (window, bucket) a bucket table needs
 static int g_lds_auto = [] { const char* e = getenv("TCGNN_LDS_AUTO"); return e ? atoi(e) : 1; }();
 static int g_lds_dbg = [] { const char* e = getenv("TCGNN_LDS_DBG"); return e ? atoi(e) : 0; }();
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
@@ -1934,8 +1935,8 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         // wide column spaces with short windows (a row shard of a multi-GPU graph: Reddit's 243 tiles per window spread over
         // N x 232 965 columns): fewer, longer buckets rather than no table - without it the shard falls back to the per-window
         // walk (measured 1.77 ms against 0.87 ms for the unsharded graph)
-        while (nb > 8 && p->total_wb < (int64_t)2 * nb * nw) nb >>= 1;
-        if (nw >= 4 * p->num_cus && p->total_wb >= (int64_t)2 * nb * nw) {
+        while (nb > 8 && p->total_wb < (int64_t)g_bucket_min_tiles * nb * nw) nb >>= 1;
+        if (nw >= 4 * p->num_cus && p->total_wb >= (int64_t)g_bucket_min_tiles * nb * nw) {
             p->nbuckets = nb;
             p->bucket_rows = (int32_t)(((int64_t)num_cols + nb - 1) / nb);
             if (p->bucket_rows < 1) p->bucket_rows = 1;
