@@ -1605,6 +1605,11 @@ static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std:
 static bool windows_balanced(const tcgnn_plan* plan) {
     return plan->nw_eff > 0 && plan->max_wb * (int64_t)plan->nw_eff <= 8 * std::max<int64_t>(plan->total_wb, 1);
 }
+// ... and when the bucket table can cut the image into ranges an XCD's 4 MB L2 holds (ogbn-products at D = 128: 8 buckets
+// of 78 MB - the range-major SDDMM then only pays for its bookkeeping: 5.70 ms against 4.93 ms per-window)
+static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
+    return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20);
+}
 
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
@@ -1739,7 +1744,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan)));
+    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
         if (const char* e = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // tuning experiments only
@@ -2058,7 +2063,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
-    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan)));
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
     hipError_t e;
     if (blocked) {
         size_t range_bytes = 4 * kRangeTargetBytes;
