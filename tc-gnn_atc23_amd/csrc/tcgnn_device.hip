@@ -70,11 +70,17 @@ struct tcgnn_plan {
     uint32_t* d_bptr = nullptr;   // [nw_eff][nbuckets + 1] tile offset of the first tile whose first column is in bucket >= k
     int32_t num_cus = 256;
     size_t bytes = 0;
-    // cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc); lds_nranges == 0: not built
-    int32_t lds_nranges = 0, lds_nwg = 0, lds_maxw = 0;   // lds_maxw: windows per wavefront the stream was laid out for (4 or 8)
-    int64_t lds_tiles = 0;
-    uint32_t* d_cell_ptr = nullptr;    // [lds_nwg * lds_nranges * 64 + 1] tile offset of cell (workgroup, range, wavefront, window slot)
-    uint32_t* d_cell_tiles = nullptr;  // [lds_tiles][32] 32 u16 row ids local to the range + 16 mask words
+    // cell streams of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc), one per range length in use (slot 0: 504-row
+    // ranges for 4-plane passes, 1: 760 rows for 2 planes, 2: 1528 rows for 1 plane, 3: 632 rows for 3 planes); nranges == 0: not built
+    struct CellStream {
+        int32_t nranges = 0, nwg = 0;
+        int64_t tiles = 0;
+        uint32_t* d_cell_ptr = nullptr;    // [nwg * nranges * 16 * maxw + 1] tile offset of cell (workgroup, range, wavefront, window slot)
+        uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
+    };
+    CellStream lds[4];
+    int32_t lds_maxw = 0;   // windows per wavefront the streams are laid out for (4 or 8)
+    bool lds_enabled = false;   // the density test passed (or mode 3 forced it): binary SpMM takes the LDS-resident kernel
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
     mutable std::vector<hipEvent_t> ev;
     mutable int ev_used = 0;
@@ -1648,14 +1654,16 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 // Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
 // condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
 static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); return (e && atoi(e) == 8) ? kLdsMaxW2 : kLdsMaxW; }();
-static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
+static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    if (p->lds_nranges > 0) return TCGNN_OK;
+    if (p->lds[slot].nranges > 0) return TCGNN_OK;
     const int nw = p->nw_eff;
     if (nw <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
-    const int nranges = (p->Nc + kLdsRows - 1) / kLdsRows;
-    const int maxw = g_lds_maxw;
+    if (p->lds_maxw == 0) p->lds_maxw = g_lds_maxw;
+    const int maxw = p->lds_maxw;
+    const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
+    const int nranges = (p->Nc + rows - 1) / rows;
     const int per_wg = kLdsWaves * maxw;
     int nwg = (nw + per_wg - 1) / per_wg;
     // spread over every CU; with 8 windows per wavefront a 64-column matrix takes two passes (grid.y), hence half the CUs per pass
@@ -1670,7 +1678,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     const int64_t nthreads = (int64_t)nw * nranges;
     hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, nw, nwg,
-                       nranges, p->Nc, maxw, d_cnt, d_firstq);
+                       nranges, p->Nc, maxw, rows, d_cnt, d_firstq);
     std::vector<uint32_t> cnt((size_t)ncell + 1);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -1684,18 +1692,18 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream) {
     e = hipMalloc(&d_tiles, (size_t)nwords * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
-    hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords);
+    hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
     hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       maxw, d_cnt, d_firstq, d_tiles);
-    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles);
+                       maxw, rows, d_cnt, d_firstq, d_tiles);
+    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `cnt` must outlive its copy
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
     (void)hipFree(d_firstq);
-    p->d_cell_ptr = d_cnt; p->d_cell_tiles = d_tiles;
-    p->lds_nwg = nwg; p->lds_tiles = ntiles; p->lds_maxw = maxw;
+    p->lds[slot].d_cell_ptr = d_cnt; p->lds[slot].d_cell_tiles = d_tiles;
+    p->lds[slot].nwg = nwg; p->lds[slot].tiles = ntiles;
     p->bytes += (size_t)(ncell + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t);
-    p->lds_nranges = nranges;
+    p->lds[slot].nranges = nranges;
     return TCGNN_OK;
 }
 
@@ -1721,22 +1729,35 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return TCGNN_OK;
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_nranges > 0));
+    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled));
     int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
-        if (plan->lds_nranges == 0) {   // forced on a plan built without the cell stream (tests, tools): build it now
-            const int brc = build_lds_cells(const_cast<tcgnn_plan*>(plan), stream);
-            if (brc) return brc;
-        }
-        SpmmLdsArgs l{plan->d_cell_ptr, plan->d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1,
-                      plan->lds_nranges, plan->nw_eff, plan->lds_nwg, g_lds_dbg, relu};
+        tcgnn_plan* mp = const_cast<tcgnn_plan*>(plan);
+        if (mp->lds_maxw == 0) mp->lds_maxw = g_lds_maxw;
         const int cdims = lds_chunk_dims(plan->lds_maxw);
         const int lfull = dpad / cdims, lrem = (dpad % cdims) / 16;
+        // a pass of 1 / 2 planes walks longer ranges than one of 3 / 4: its own cell stream, built the first time it is needed
+        // (plan creation builds the 4-plane one; a first call with another width synchronises the stream once)
+        auto pass = [&](int nt, int chunk0, int nchunks) -> int {
+            const int slot = lds_stream_of(nt, plan->lds_maxw);
+            if (plan->lds[slot].nranges == 0) {
+                const int brc = build_lds_cells(mp, stream, slot);
+                if (brc) return brc;
+            }
+            const tcgnn_plan::CellStream& cs = plan->lds[slot];
+            SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, chunk0, plan->Nc + 1,
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu};
+            HIP_TRY(launch_lds_any(plan->lds_maxw, nt, l, nchunks, stream));
+            return TCGNN_OK;
+        };
+        // (streams are built before the timer starts so a first call does not charge the build to the kernel)
+        if (lfull && plan->lds[lds_stream_of(cdims / 16, plan->lds_maxw)].nranges == 0) { const int b = build_lds_cells(mp, stream, lds_stream_of(cdims / 16, plan->lds_maxw)); if (b) return b; }
+        if (lrem && plan->lds[lds_stream_of(lrem, plan->lds_maxw)].nranges == 0) { const int b = build_lds_cells(mp, stream, lds_stream_of(lrem, plan->lds_maxw)); if (b) return b; }
         KernelTimer timer(plan, stream);
-        if (lfull) { l.chunk0 = 0; HIP_TRY(launch_lds_any(plan->lds_maxw, cdims / 16, l, lfull, stream)); }
-        if (lrem) { l.chunk0 = lfull; HIP_TRY(launch_lds_any(plan->lds_maxw, lrem, l, 1, stream)); }
+        if (lfull) { const int r2 = pass(cdims / 16, 0, lfull); if (r2) return r2; }
+        if (lrem) { const int r2 = pass(lrem, lfull, 1); if (r2) return r2; }
         return TCGNN_OK;
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu};
@@ -1857,7 +1878,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
-    (void)hipFree(plan->d_cell_ptr); (void)hipFree(plan->d_cell_tiles);
+    for (auto& cs : plan->lds) { (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -1963,9 +1984,10 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     // big enough that the gather walks would leave the L2 (tcgnn_lds_spmm.inc).  TCGNN_LDS_AUTO=0 disables it.
     if (g_lds_auto && nw >= 4 * p->num_cus && (size_t)num_cols * 128 >= kBlockedMinBytes) {
         const double uses = (double)num_edges * (kLdsWaves * kLdsMaxW * kWinRows) / ((double)std::max(num_rows, 1) * (double)std::max(num_cols, 1));
-        const double cells = (double)nw * ((double)num_cols / kLdsRows + 1.0);
+        const double cells = (double)nw * ((double)num_cols / (lds_stream_buf_rows(0) - 8) + 1.0);
         if (uses >= 1.5 && cells < 1.0e9) {
-            const int rc = build_lds_cells(p, stream);
+            p->lds_enabled = true;
+            const int rc = build_lds_cells(p, stream, 0);
             if (rc) return bail(rc);
         }
     }
@@ -1986,7 +2008,7 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
     info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
     info->canonical = plan->canonical; info->waves_per_window = plan->waves;
-    info->column_buckets = plan->nbuckets; info->lds_ranges = plan->lds_nranges;
+    info->column_buckets = plan->nbuckets; info->lds_ranges = plan->lds[0].nranges;
     return TCGNN_OK;
 }
 
