@@ -1729,7 +1729,9 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return TCGNN_OK;
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled));
+    // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
+    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled)) &&
+                     (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
     int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
     if (rc) return rc;
     if (plan->nw_eff == 0) return TCGNN_OK;
