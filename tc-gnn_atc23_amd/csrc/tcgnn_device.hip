@@ -1643,6 +1643,9 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
         if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
+        else if ((size_t)D * 64 * sizeof(float) <= 48 * 1024)
+            hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
+                               d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
         else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
     } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
     else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
