@@ -110,4 +110,4 @@ def time_training(rowptr, col, features, labels, n_hidden, n_classes, epochs, n_
         opt.zero_grad()
         loss.backward()
         opt.step()
-    return {"train_ms": (time.perf_counter() - t0) * 1e3 / max(epochs, 1), "final_loss": float(loss), "threads": threads or O.num_threads()}
+    return {"train_ms": (time.perf_counter() - t0) * 1e3 / max(epochs, 1), "final_loss": float(loss.detach()), "threads": threads or O.num_threads()}
