@@ -10,6 +10,10 @@
 //                      (wmma::__float_to_tf32, TCGNN_kernel.cu:438-444) without fp16's range limit.
 //   spmm_kernel        TCGNN_kernel.cu:336-454 (binary A) and :459-578 (edge-valued A).
 //   sddmm_kernel       TCGNN_kernel.cu:584-727.
+//   spmm_blocked_kernel / spmm_lds_kernel (tcgnn_lds_spmm.inc) / spmm_small_kernel
+//                      the same SpMM for big feature matrices (column-range-blocked gather), dense graphs (column ranges
+//                      resident in LDS) and launch-latency-sized graphs (one launch, fp32 MFMA on fp32 X).
+//   agnn_kernel        the SDDMM + edge-weighted SpMM pair of gnn_conv.py:115-158 in one gather, forward and backward.
 //   *_csr_kernel       slow-but-correct HIP paths for CSRs whose rows are not strictly increasing
 //                      (the packed edge-offset table assumes canonical rows).
 //
