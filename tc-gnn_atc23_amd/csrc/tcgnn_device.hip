@@ -1617,8 +1617,10 @@ static bool windows_balanced(const tcgnn_plan* plan) {
 }
 // ... and when the bucket table can cut the image into ranges an XCD's 4 MB L2 holds (ogbn-products at D = 128: 8 buckets
 // of 78 MB - the range-major SDDMM then only pays for its bookkeeping: 5.70 ms against 4.93 ms per-window)
+// ... and when there are enough windows for two workgroups of persistent wavefronts per CU at 4 windows each: with 3750 /
+// 6250 windows the range-blocked walk left the chip a quarter full (0.33 / 1.03 ms against 0.13 / 0.66 ms per-window).
 static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
-    return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20);
+    return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
 }
 
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
@@ -1961,7 +1963,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
     p->canonical = flags[1] ? 0 : 1;
     {   // column buckets for the range-blocked SpMM: only when windows are long (>= 2 tiles per bucket on
-        // average) and numerous enough to fill the chip with one wavefront per 4 windows
+        // average) and numerous enough to fill the chip with one wavefront per 4 windows (below)
         hipDeviceProp_t prop;
         int devid = 0;
         if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess) p->num_cus = prop.multiProcessorCount;
@@ -1992,7 +1994,14 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     // CU's LDS is used more than once by the 64 windows resident there (Reddit: 2.2 uses; ogbn-products: 0.02) and
     // big enough that the gather walks would leave the L2 (tcgnn_lds_spmm.inc).  TCGNN_LDS_AUTO=0 disables it.
     if (g_lds_auto && nw >= 4 * p->num_cus && (size_t)num_cols * 128 >= kBlockedMinBytes) {
-        const double uses = (double)num_edges * (kLdsWaves * kLdsMaxW * kWinRows) / ((double)std::max(num_rows, 1) * (double)std::max(num_cols, 1));
+        // windows a workgroup will actually hold: the stream spreads them over every CU (build_lds_cells), so a graph with few
+        // windows gives each CU only a handful to amortise its pass over X (N = 60 k, 20 M edges: 16 per workgroup - the LDS
+        // kernel then ran 0.163 ms against 0.128 ms for the per-window walk)
+        const int per_wg = kLdsWaves * kLdsMaxW;
+        int lnwg = (nw + per_wg - 1) / per_wg;
+        if (lnwg < p->num_cus) lnwg = std::max(lnwg, std::min(p->num_cus, (nw + kLdsWaves - 1) / kLdsWaves));
+        const double wpw = (double)nw / std::max(lnwg, 1);
+        const double uses = (double)num_edges * (wpw * kWinRows) / ((double)std::max(num_rows, 1) * (double)std::max(num_cols, 1));
         const double cells = (double)nw * ((double)num_cols / (lds_stream_buf_rows(0) - 8) + 1.0);
         if (uses >= 1.5 && cells < 1.0e9) {
             p->lds_enabled = true;
