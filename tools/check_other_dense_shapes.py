@@ -28,4 +28,14 @@ for n, nnz in ((100000, 80_000_000), (60000, 20_000_000), (400000, 120_000_000))
         print("N=%d nnz=%d D=%d lds_ranges=%d buckets=%d : auto %.3f ms, plain %.3f, blocked %.3f | max diff auto-plain %.2e auto-blocked %.2e (scaled)" % (
             n, E, D, info["lds_ranges"], info["column_buckets"], out[0][0], out[1][0], out[2][0],
             ((out[0][1] - out[1][1]).abs() / scale).max().item(), ((out[0][1] - out[2][1]).abs() / scale).max().item()), flush=True)
+        # SDDMM and the fused AGNN forward: automatic choice against the two forced walks
+        for name, fn in (("sddmm", lambda: TCGNN.forward_ef(X, *meta)[0]), ("agnn_fwd", lambda: TCGNN.agnn_fused_forward(X / D ** 0.5, rp, col, torch.tensor([0.9], device=dev), bp, e2c, e2r)[0])):
+            tt = {}
+            for mode in (0, 1, 2):
+                c.lib.tcgnn_set_spmm_mode(mode)
+                fn(); TCGNN.kernel_timing(*meta, max_calls=6)
+                for _ in range(6): fn()
+                tt[mode] = np.median(TCGNN.kernel_timing(*meta))
+            c.lib.tcgnn_set_spmm_mode(0); TCGNN.kernel_timing(*meta, max_calls=0)
+            print("   %-8s D=%d: auto %.3f ms, per-window %.3f, range-major %.3f" % (name, D, tt[0], tt[1], tt[2]), flush=True)
     TCGNN.clear_plan_cache()
