@@ -9,7 +9,7 @@ import TCGNN, tcgnn_graph as G, tcgnn_capi as c
 which = sys.argv[1]; D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 if len(sys.argv) > 3: c.lib.tcgnn_set_spmm_mode(int(sys.argv[3]))
 dev = torch.device("cuda:0")
-n, nnz, _, _ = G.SHAPES["reddit"]
+n, nnz, _, _ = G.SHAPES[os.environ.get("TCGNN_PROFILE_SHAPE", "reddit")]
 rp, col = G.synthetic_csr(n, nnz, seed=0, device=dev)
 E = col.numel(); nw = (n + 15) // 16
 bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
