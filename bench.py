@@ -335,6 +335,14 @@ def multi_gpu(args):
     t_other = sync_time(other, max(3, args.steps // 5), 2, barrier) * args.steps / max(3, args.steps // 5)
     t_nox = t_other if exchange else elapsed
     t_withx = elapsed if exchange else t_other
+    # ---- the exchange with fp16 on the wire (each rank converts its own rows; the kernels' image, not fp32 X, is gathered)
+    t_wire16 = float("nan")
+    try:
+        w16 = lambda: shard.spmm(x_local, wire="fp16")
+        t_wire16 = sync_time(w16, max(3, args.steps // 5), 2, barrier) * args.steps / max(3, args.steps // 5)
+    except Exception as exc:   # an extra: must never take the headline down
+        if rank == 0:
+            print("fp16-exchange leg failed: %s" % str(exc)[:300], file=sys.stderr)
     # ---- one sharded GCN training epoch (2 layers, hidden D, main_tcgnn.py:146-181 on the shard): X W locally, all-gather +
     #      local SpMM forward and backward in both layers, one all-reduce of the weight gradients
     gcn_ms = float("nan")
@@ -350,7 +358,7 @@ def multi_gpu(args):
     except Exception as exc:   # the extra leg must never take the headline down
         if rank == 0:
             print("sharded GCN leg failed: %s" % str(exc)[:300], file=sys.stderr)
-    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16], dtype=torch.float64, device=dev)
     mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     out = None
@@ -374,7 +382,8 @@ def multi_gpu(args):
                       "ms_per_step_with_exchange": round(t_x * 1e3 / args.steps, 4),
                       "exchange_fraction_if_exchanged": round(max(0.0, 1.0 - t_local / t_x), 4),
                       "gathered_X_bytes": int(shard.layout.num_cols) * D * 4,
-                      "gcn_ms_per_epoch_sharded": None if np.isnan(float(mx[5])) else round(float(mx[5]), 3)},
+                      "gcn_ms_per_epoch_sharded": None if np.isnan(float(mx[5])) else round(float(mx[5]), 3),
+                      "ms_per_step_with_fp16_exchange": None if np.isnan(float(mx[6])) else round(float(mx[6]) * 1e3 / args.steps, 4)},
         }
     dist.barrier()
     dist.destroy_process_group()
@@ -391,7 +400,15 @@ def main():
     else:
         out = single_gpu(args)
     if out is not None:
-        print(json.dumps(out))
+        # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe or a file and would come
+        # out AFTER this line at exit: drain it first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

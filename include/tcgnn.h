@@ -181,6 +181,21 @@ int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D,
 int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_gate, float* d_Y, int32_t D,
                      int32_t flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Pre-staged operand (no counterpart in the reference, which is single-GPU).  The kernels read a scaled fp16 image of X that
+ * tcgnn_spmm builds per call inside the workspace.  A caller may build it itself - in a row-sharded run every rank converts
+ * only ITS rows and the fp16 image, not fp32 X, crosses the fabric (half the bytes of the all-gather, no staging of the
+ * gathered matrix on every rank):
+ *   image  = 256-byte header (word 0: bit pattern of max|X| over the WHOLE matrix, e.g. after an all-reduce(MAX) of the
+ *            per-rank words) followed by (plan's num_cols + 1) rows of tcgnn_x16_pitch(D) halves, the last row all zero;
+ *   tcgnn_stage_absmax : atomicMax of the |X| bit patterns of n elements into *d_word (zero it first);
+ *   tcgnn_stage_rows   : `rows` rows of X -> rows + 1 image rows at d_dst (the extra row is zero), scaled by *d_absmax_word
+ *                        exactly as tcgnn_spmm would;
+ *   tcgnn_spmm_staged  : Y = A_bin * X from such an image (gather walks; results identical to tcgnn_spmm on the same walk). */
+int tcgnn_x16_pitch(int32_t D);
+int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream);
+int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, void* stream);
+int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream);
+
 /* Y[N,D] = A_val * X with A_val[r,c] = d_edge_val[e] for CSR edge e = (r,c).
  * Replaces TCGNN.forward_AGNN (TCGNN.cpp:93-118); d_edge_val is row 0 of edgeAttention[H,E]. */
 int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y,

@@ -1717,8 +1717,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
 }
 
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
-                    void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr) {
-    if (!plan || D < 1 || (plan->N > 0 && (!d_X || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
+                    void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr) {
+    if (!plan || D < 1 || (plan->N > 0 && ((!d_X && !d_staged) || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->N == 0) return TCGNN_OK;
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
@@ -1730,7 +1730,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return TCGNN_OK;
     }
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
-    if (!d_val && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
+    if (!d_val && !d_staged && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
         const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu};
         KernelTimer timer(plan, stream);
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
@@ -1739,10 +1739,17 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
-    const bool lds = !d_val && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled)) &&
+    const bool lds = !d_val && !d_staged && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled)) &&
                      (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
-    int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
-    if (rc) return rc;
+    if (d_staged) {   // the caller built the (row-major) fp16 image itself: tcgnn_spmm_staged
+        hdr = static_cast<const uint32_t*>(d_staged);
+        x16 = reinterpret_cast<const _Float16*>(static_cast<const char*>(d_staged) + kHdrBytes);
+        dpad = round_up(D, 16);
+        pitch = x16_pitch(dpad);
+    } else {
+        const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
+        if (rc) return rc;
+    }
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
         tcgnn_plan* mp = const_cast<tcgnn_plan*>(plan);
@@ -2075,6 +2082,37 @@ int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_ga
                      void* ws, size_t ws_bytes, void* stream) {
     if (flags & ~TCGNN_FUSE_RELU) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_fused: unknown flag bits 0x%x", flags & ~TCGNN_FUSE_RELU);
     return run_spmm(plan, d_X, nullptr, d_Y, D, ws, ws_bytes, stream, (flags & TCGNN_FUSE_RELU) ? 1 : 0, d_gate);
+}
+
+int tcgnn_x16_pitch(int32_t D) { return D < 1 ? 0 : x16_pitch(round_up(D, 16)); }
+
+int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream_v) {
+    if (n < 0 || (n > 0 && !d_X) || !d_word) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_absmax: null argument");
+    if (n == 0) return TCGNN_OK;
+    const int grid = (int)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word);
+    HIP_TRY(hipGetLastError());
+    return TCGNN_OK;
+}
+
+int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, void* stream_v) {
+    if (rows < 0 || D < 1 || (rows > 0 && !d_X) || !d_absmax_word || !d_dst) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_rows: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_dst) & 15) != 0) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_rows: destination must be 16-byte aligned");
+    const int dpad = round_up(D, 16), pitch = x16_pitch(dpad);
+    const int64_t chunks = ((int64_t)rows + 1) * (dpad / 8);
+    const unsigned cgrid = (unsigned)((chunks + 255) / 256);
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
+    _Float16* dst = static_cast<_Float16*>(d_dst);
+    if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, rows, D, dpad, pitch, dst, d_absmax_word, (const float*)nullptr);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, rows, D, dpad, pitch, dst, d_absmax_word, (const float*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return TCGNN_OK;
+}
+
+int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream) {
+    if (!d_image || (reinterpret_cast<uintptr_t>(d_image) & 255)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_staged: the image must be 256-byte aligned");
+    return run_spmm(plan, nullptr, nullptr, d_Y, D, nullptr, 0, stream, 0, nullptr, d_image);
 }
 
 int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y, int32_t D,

@@ -115,6 +115,44 @@ class HipShardOps:
             self.c.check(self.c.lib.tcgnn_spmm(self.plan, Xg.data_ptr(), Y.data_ptr(), D, ws, nb, torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_spmm")
         return Y
 
+    def spmm_fp16_exchange(self, x_local, layout, rank, group=None):
+        """Y_local = A_local @ X with fp16 on the wire: this rank converts ITS rows to the kernels' scaled fp16 image (global
+        max|X| from a one-word all-reduce), the image slices are all-gathered (half the bytes of the fp32 gather, and no rank
+        stages the whole gathered matrix again) and the SpMM reads the image directly (tcgnn_spmm_staged)."""
+        c, dev = self.c, self.dev
+        rows, D = x_local.shape
+        H, world = layout.H, layout.world
+        pitch = c.lib.tcgnn_x16_pitch(D)
+        key = ("wire16", D)
+        buf = getattr(self, "_wire", {}).get(key)
+        if buf is None:
+            image = torch.zeros(256 + (self.num_cols + 1) * pitch * 2 + 256, dtype=torch.uint8, device=dev)
+            off = (-image.data_ptr()) % 256
+            image = image[off: off + 256 + (self.num_cols + 1) * pitch * 2]
+            body = image[256:].view(torch.float16).view(self.num_cols + 1, pitch)
+            send = torch.zeros(H + 1, pitch, dtype=torch.float16, device=dev)
+            word = image[:4].view(torch.int32)
+            buf = (image, body, send, word)
+            if not hasattr(self, "_wire"):
+                self._wire = {}
+            self._wire[key] = buf
+        image, body, send, word = buf
+        st = torch.cuda.current_stream(dev).cuda_stream
+        x_local = x_local.contiguous()
+        with torch.cuda.device(dev):
+            word.zero_()
+            c.check(c.lib.tcgnn_stage_absmax(x_local.data_ptr(), rows * D, word.data_ptr(), st), "tcgnn_stage_absmax")
+            if world > 1:
+                dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)   # bit patterns of non-negative floats order like ints
+            c.check(c.lib.tcgnn_stage_rows(x_local.data_ptr(), rows, D, word.data_ptr(), send.data_ptr(), st), "tcgnn_stage_rows")
+            if world > 1:
+                dist.all_gather_into_tensor(body[: world * H].view(-1), send[:H].view(-1), group=group)
+            else:
+                body[:H].copy_(send[:H])
+            Y = torch.empty(self.rows, D, device=dev)
+            c.check(c.lib.tcgnn_spmm_staged(self.plan, image.data_ptr(), Y.data_ptr(), D, st), "tcgnn_spmm_staged")
+        return Y
+
     def spmm_val(self, Xg, val):
         self._check(Xg)
         D = Xg.shape[1]
@@ -219,7 +257,10 @@ class RowShard:
         """Differentiable Y_local = A_local @ all_gather(X)."""
         return _GatherSpmm.apply(x_local, self)
 
-    def spmm(self, x_local):
+    def spmm(self, x_local, wire="fp32"):
+        """wire="fp16": the exchange carries the kernels' fp16 image instead of fp32 X (HipShardOps.spmm_fp16_exchange)."""
+        if wire == "fp16" and hasattr(self.ops, "spmm_fp16_exchange"):
+            return self.ops.spmm_fp16_exchange(x_local, self.layout, self.rank, self.group)
         return self.ops.spmm(self.gather(x_local))
 
     def spmm_val(self, x_local, val_local):

@@ -452,6 +452,32 @@ def test_gcn_layer_with_fused_relu_gives_the_same_values_and_gradients(dev, T):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("D", [64, 41])
+def test_sharded_spmm_with_fp16_on_the_wire_equals_the_fp32_gather(dev, T, D):
+    """tcgnn_stage_absmax / tcgnn_stage_rows / tcgnn_spmm_staged (the pre-staged image a rank would all-gather instead of
+    fp32 X) against the ordinary path on one rank's shard: same kernel, same operands, identical results."""
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    rp, col = graphs.uniform_graph(5000, 60, seed=41)
+    n = len(rp) - 1
+    shard = S.RowShard(rp, col, rank=0, world_size=1, device=dev)
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((n, D)).astype(np.float32) * 37.0
+    (tX,) = to_dev(dev, X)
+    try:
+        for mode in (1, 2):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            a = shard.spmm(tX)
+            b = shard.spmm(tX, wire="fp16")
+            assert torch.equal(a, b), mode
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    bp, e2c, e2r = (t.cpu().numpy() for t in shard.ops.meta[2:])
+    Y64, absY = O.spmm_f64(X, rp, col)
+    assert_parity(b.cpu().numpy(), O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32), Y64, absY, "staged spmm", False)
+    shard.ops.close()
+
+
 def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
     """tcgnn_harness.time_training(hip_graph=True) captures forward + loss + backward + Adam step once and replays it: every
     kernel of the path must be capturable (no allocation outside torch's pool, no synchronisation, current-stream launches)

@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_the_header_declares():
     import tcgnn_capi as c
     hdr = open(os.path.join(ROOT, "include", "tcgnn.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(tcgnn_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(tcgnn_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(c.SIGNATURES), (declared ^ set(c.SIGNATURES))
     for name in declared:
