@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick on-GPU diagnostics: max errors of the three kernels against the oracle over a grid of
+"""CHECKER-SIDE UTILITY (lives under oracle/; nothing in the product imports it).  Quick on-GPU diagnostics: max errors of the three kernels against the oracle over a grid of
 graph shapes and feature widths, plus first timings.  Not a test (tests/test_gpu_parity.py is);
 prints numbers so a failure can be localised from one gpurun call."""
 import os, sys, time

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Host sparse-graph translation: this repo's tcgnn_preprocess against the reference's own TCGNN.preprocess (the unmodified
+"""CHECKER-SIDE UTILITY (lives under oracle/: it loads the compiled reference; nothing in the product imports it).
+Host sparse-graph translation: this repo's tcgnn_preprocess against the reference's own TCGNN.preprocess (the unmodified
 TCGNN.cpp compiled into oracle/_ref by oracle/build_ref.sh - only possible where /root/reference exists), same graph, same
 machine.  Prints ns per edge for both and checks the outputs are identical."""
 import os, sys, time
