@@ -156,7 +156,8 @@ def single_gpu(args):
     blocked = info["column_buckets"] > 0 and (n + 1) * pitch * 2 > (6 << 20)   # the launcher's rule (tcgnn_device.hip run_spmm)
     kname = ("spmm_blocked_kernel<NT=%d,MAXW=%d>" % (nt, 4 if nt <= 4 else 2)) if blocked else ("spmm_kernel<NT=%d,WAVES=%d>" % (nt, info["waves_per_window"]))
     if info.get("lds_ranges", 0) > 0:   # dense graph: the LDS-resident column-range kernel (64 feature columns per pass)
-        kname = "spmm_lds_kernel<NT=%d>" % min(4, nt)
+        wide = D > 48 and os.environ.get("TCGNN_LDS_MAXW", "") != "4"   # run_spmm's layout rule
+        kname = "spmm_lds_kernel<NT=%d,MAXW=%d>" % ((2, 8) if wide else (min(4, nt), 4))
     out = {
         "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
         "value": round(gteps, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

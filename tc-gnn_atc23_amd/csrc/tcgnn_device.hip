@@ -74,16 +74,15 @@ struct tcgnn_plan {
     uint32_t* d_bptr = nullptr;   // [nw_eff][nbuckets + 1] tile offset of the first tile whose first column is in bucket >= k
     int32_t num_cus = 256;
     size_t bytes = 0;
-    // cell streams of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc), one per range length in use (slot 0: 504-row
-    // ranges for 4-plane passes, 1: 760 rows for 2 planes, 2: 1528 rows for 1 plane, 3: 632 rows for 3 planes); nranges == 0: not built
+    // cell streams of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc), one per range length in use (lds_stream_of: 4 windows per
+    // wavefront x 4 / 2 / 1 / 3 planes, 8 windows x 2 / 1 planes); nranges == 0: not built
     struct CellStream {
         int32_t nranges = 0, nwg = 0;
         int64_t tiles = 0;
         uint32_t* d_cell_ptr = nullptr;    // [nwg * nranges * 16 * maxw + 1] tile offset of cell (workgroup, range, wavefront, window slot)
         uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
     };
-    CellStream lds[4];
-    int32_t lds_maxw = 0;   // windows per wavefront the streams are laid out for (4 or 8)
+    CellStream lds[6];   // (kLdsStreams)
     bool lds_enabled = false;   // the density test passed (or mode 3 forced it): binary SpMM takes the LDS-resident kernel
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
     mutable std::vector<hipEvent_t> ev;
@@ -1662,15 +1661,14 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 
 // Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
 // condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
-static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); return (e && atoi(e) == 8) ? kLdsMaxW2 : kLdsMaxW; }();
+static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();   // 0: by width
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (p->lds[slot].nranges > 0) return TCGNN_OK;
     const int nw = p->nw_eff;
     if (nw <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
-    if (p->lds_maxw == 0) p->lds_maxw = g_lds_maxw;
-    const int maxw = p->lds_maxw;
+    const int maxw = lds_stream_maxw(slot);
     const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
     const int nranges = (p->Nc + rows - 1) / rows;
     const int per_wg = kLdsWaves * maxw;
@@ -1753,29 +1751,32 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
         tcgnn_plan* mp = const_cast<tcgnn_plan*>(plan);
-        if (mp->lds_maxw == 0) mp->lds_maxw = g_lds_maxw;
-        const int cdims = lds_chunk_dims(plan->lds_maxw);
-        const int lfull = dpad / cdims, lrem = (dpad % cdims) / 16;
-        // a pass of 1 / 2 planes walks longer ranges than one of 3 / 4: its own cell stream, built the first time it is needed
-        // (plan creation builds the 4-plane one; a first call with another width synchronises the stream once)
-        auto pass = [&](int nt, int chunk0, int nchunks) -> int {
-            const int slot = lds_stream_of(nt, plan->lds_maxw);
-            if (plan->lds[slot].nranges == 0) {
-                const int brc = build_lds_cells(mp, stream, slot);
-                if (brc) return brc;
-            }
-            const tcgnn_plan::CellStream& cs = plan->lds[slot];
-            SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, chunk0, plan->Nc + 1,
-                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu};
-            HIP_TRY(launch_lds_any(plan->lds_maxw, nt, l, nchunks, stream));
-            return TCGNN_OK;
-        };
-        // (streams are built before the timer starts so a first call does not charge the build to the kernel)
-        if (lfull && plan->lds[lds_stream_of(cdims / 16, plan->lds_maxw)].nranges == 0) { const int b = build_lds_cells(mp, stream, lds_stream_of(cdims / 16, plan->lds_maxw)); if (b) return b; }
-        if (lrem && plan->lds[lds_stream_of(lrem, plan->lds_maxw)].nranges == 0) { const int b = build_lds_cells(mp, stream, lds_stream_of(lrem, plan->lds_maxw)); if (b) return b; }
+        // Layout by width: whole 64-column chunks go as two 32-column passes of the 8-windows-per-wavefront layout (half the
+        // workgroups stream each plane pair, 760-row ranges: Reddit D = 64 0.70 vs 0.82 ms), what is left over (1-3 planes)
+        // as one pass of the 4-window layout.  TCGNN_LDS_MAXW = 4 / 8 forces one layout for every pass (tests, timing).
+        struct Pass { int maxw, nt, chunk0, nchunks; } passes[2]; int npass = 0;
+        if (g_lds_maxw) {
+            const int cd = lds_chunk_dims(g_lds_maxw);
+            if (dpad / cd) passes[npass++] = {g_lds_maxw, cd / 16, 0, dpad / cd};
+            if (dpad % cd) passes[npass++] = {g_lds_maxw, (dpad % cd) / 16, dpad / cd, 1};
+        } else {
+            if (dpad / 64) passes[npass++] = {kLdsMaxW2, 2, 0, 2 * (dpad / 64)};
+            if (dpad % 64) passes[npass++] = {kLdsMaxW, (dpad % 64) / 16, dpad / 64, 1};
+        }
+        // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
+        // one a 64-column matrix uses; a first call with another width synchronises the stream once) and before the timer
+        // starts, so a first call does not charge the build to the kernel
+        for (int i = 0; i < npass; ++i) {
+            const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
+            if (plan->lds[slot].nranges == 0) { const int b = build_lds_cells(mp, stream, slot); if (b) return b; }
+        }
         KernelTimer timer(plan, stream);
-        if (lfull) { const int r2 = pass(cdims / 16, 0, lfull); if (r2) return r2; }
-        if (lrem) { const int r2 = pass(lrem, lfull, 1); if (r2) return r2; }
+        for (int i = 0; i < npass; ++i) {
+            const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
+            SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu};
+            HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
+        }
         return TCGNN_OK;
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu};
@@ -2012,7 +2013,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         const double cells = (double)nw * ((double)num_cols / (lds_stream_buf_rows(0) - 8) + 1.0);
         if (uses >= 1.5 && cells < 1.0e9) {
             p->lds_enabled = true;
-            const int rc = build_lds_cells(p, stream, 0);
+            const int rc = build_lds_cells(p, stream, g_lds_maxw == kLdsMaxW ? 0 : lds_stream_of(2, kLdsMaxW2));   // what a 64-column matrix takes
             if (rc) return bail(rc);
         }
     }
@@ -2033,7 +2034,8 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     info->num_nodes = plan->N; info->num_windows = plan->nw; info->num_edges = plan->E;
     info->tc_blocks = plan->tc_blocks; info->wide_blocks = plan->total_wb; info->plan_bytes = (int64_t)plan->bytes;
     info->canonical = plan->canonical; info->waves_per_window = plan->waves;
-    info->column_buckets = plan->nbuckets; info->lds_ranges = plan->lds[0].nranges;
+    info->column_buckets = plan->nbuckets; info->lds_ranges = 0;
+    for (int i = 0; i < kLdsStreams; ++i) if (plan->lds[i].nranges > info->lds_ranges) info->lds_ranges = plan->lds[i].nranges;   // finest stream built so far
     return TCGNN_OK;
 }
 

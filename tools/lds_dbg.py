@@ -21,6 +21,9 @@ TCGNN.forward(X, *meta); TCGNN.kernel_timing(*meta, max_calls=10)
 for _ in range(10): TCGNN.forward(X, *meta)
 t = TCGNN.kernel_timing(*meta)
 if int(os.environ.get("TCGNN_LDS_DBG", "0")) & 16:
-    y = TCGNN.forward(X, *meta)[0].flatten()[:8].cpu().numpy()
-    print("cycles per range (100 MHz ticks x?): wave0 issue/mult/wait/barrier", y[:4] / 463, " wave9", y[4:] / 463)
+    y = TCGNN.forward(X, *meta)[0].flatten()[:128].cpu().numpy()
+    nr = TCGNN.plan_info(*meta)["lds_ranges"]
+    print("cycles per range (%d ranges), rows = wavefronts of workgroup 0, columns = fill issue / multiply / wait / barrier (mean cycles), pad refills (total), longest multiply, longest wait, tiles (total)" % nr)
+    y = y.reshape(16, 8); y[:, :4] /= nr
+    print(np.round(y).astype(int))
 print("dbg=%s D=%d: %.3f ms (min %.3f)  %s" % (os.environ.get("TCGNN_LDS_DBG", "0"), D, np.median(t), np.min(t), TCGNN.plan_info(*meta)))
