@@ -318,11 +318,13 @@ def test_lds_resident_range_kernel_matches_oracle_and_plain_walk(dev, T, D, shap
     for mode in (1, 3):
         assert_parity(out[mode], ref, Y64, absY, "spmm mode %d" % mode)
 
-def test_lds_resident_range_kernel_with_eight_windows_per_wavefront():
-    """The alternative layout of the LDS-resident kernel (TCGNN_LDS_MAXW=8: 8 windows per wavefront, 32 feature columns
-    per pass; measured slower on Reddit, kept selectable) is read from the environment when the library loads, so the
-    parity test above is re-run in a child process with the variable set."""
-    env = dict(os.environ, TCGNN_LDS_MAXW="8")
+@pytest.mark.parametrize("maxw", ["4", "8"])
+def test_lds_resident_range_kernel_with_one_layout_forced(maxw):
+    """By default whole 64-column chunks run in the 8-windows-per-wavefront layout and the 1-3 planes left over in the
+    4-window one.  TCGNN_LDS_MAXW forces one layout for every pass (4: 64 columns per pass incl. the 4-plane kernel;
+    8: 32 columns per pass incl. the 1-plane kernel); it is read when the library loads, so the parity test above is
+    re-run in a child process with the variable set."""
+    env = dict(os.environ, TCGNN_LDS_MAXW=maxw)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "test_lds_resident_range_kernel_matches_oracle_and_plain_walk and (64 or 41 or 160)"],
                        env=env, capture_output=True, text=True, timeout=600)
