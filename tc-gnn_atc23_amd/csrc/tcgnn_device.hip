@@ -344,6 +344,12 @@ typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // LDS store issued from asm (no destination register, so nothing can be in flight into a VGPR);
 // LDS operations of one wavefront execute in order, a later block read sees the data.
+// (mask & a) | (~mask & b) in one instruction (hipcc otherwise spends a compare and a select on the loop-invariant b)
+__device__ __forceinline__ uint32_t bitfield_select(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void lds_write_b32(uint32_t lds_byte_addr, float v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
 }
@@ -1215,34 +1221,32 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             // ---- edge weights of row i for my eight tile columns (branch-free; 10-bit RNA rounding done in integer
             //      arithmetic, after which the round-toward-zero pack conversion is exact)
             const uint32_t byte = (cur.m >> (8 * g)) & 0xffu;
-            uint32_t kpos[8];                                   // rank of column j among row i's edges inside my run
-            kpos[0] = 0u;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) kpos[j] = kpos[j - 1] + ((byte >> (j - 1)) & 1u);
-            [[maybe_unused]] const uint32_t spos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);
+            // (the tile loop is VALU-bound - 160 VALU instructions per tile before this form - so the eight columns are
+            // handled with masks instead of compares and selects: mk = all-ones where the edge exists; the second scale
+            // factor is 1.0 unless the exponent needs two steps, and multiplying by it is exact)
+            [[maybe_unused]] uint32_t kpos = 0u;                // backward: rank of column j among row i's edges inside my run
+            [[maybe_unused]] uint32_t wpos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);   // forward: its staging slot
             uint32_t rb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bool on = (byte >> j) & 1u;
+                const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);   // (one v_bfe_i32)
                 const float sraw = S[j >> 2][j & 3];
+                const float sc = (sraw * inv_a) * inv_b;
                 float att_s;
                 if constexpr (BWD) {
-                    const uint32_t kk = kpos[j] + (uint32_t)cur.sh;                  // position in the eight fetched floats
+                    const uint32_t kk = kpos + (uint32_t)cur.sh;                     // position in the eight fetched floats
                     const floatx4 sv = __builtin_bit_cast(floatx4, (kk & 4u) ? q[2 * KS + 1] : q[2 * KS]);
                     const float v01 = (kk & 1u) ? sv[1] : sv[0];
                     const float v23 = (kk & 1u) ? sv[3] : sv[2];
                     att_s = ((kk & 2u) ? v23 : v01) * c_val;                         // = fl32(w * ef) * 2^ka
-                    float sc = sraw * inv_a;
-                    if (two_step) sc *= inv_b;
-                    dsum += on ? sc * (float)(int32_t)cur.c[j >> 2][j & 3] : 0.0f;
+                    dsum += __uint_as_float(__float_as_uint(sc * (float)(int32_t)cur.c[j >> 2][j & 3]) & mk);
+                    kpos -= mk;
                 } else {
-                    float sc = sraw * inv_a;
-                    if (two_step) sc *= inv_b;
-                    lds_write_b32(on ? spos + (kpos[j] << 2) : junk, sc);
+                    lds_write_b32(bitfield_select(mk, wpos, junk), sc);
+                    wpos -= mk << 2;
                     att_s = sc * c_val;                                              // = fl32(w * ef) * 2^ka
                 }
-                const uint32_t u = on ? __float_as_uint(att_s) : 0u;
-                rb[j] = (u + 0x1000u) & 0xffffe000u;
+                rb[j] = ((__float_as_uint(att_s) & mk) + 0x1000u) & 0xffffe000u;
             }
             half8 a16;
 #pragma unroll

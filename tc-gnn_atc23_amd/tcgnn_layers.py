@@ -18,10 +18,13 @@ through ef into H; both are reproduced because the golden fixtures captured from
 The operators come from `backend()`: the TCGNN module of this package (HIP kernels).  Tests on a
 machine without a GPU may install another object with the same three functions via set_backend().
 """
+import contextlib
 import math
 import time
+import warnings
 
 import torch
+import torch.nn.functional as F
 
 n_heads = 1  # gnn_conv.py:10
 USE_FUSED_AGNN = True  # tests switch it off to compare with the separate calls
@@ -62,6 +65,44 @@ def tall_tn_mm(A, B):
     return out
 
 
+@contextlib.contextmanager
+def _rocblas_preferred():
+    """torch's BLAS preference set to rocBLAS for the duration (restored on exit; host-side state, safe under graph capture)."""
+    prev = None
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # "experimental feature" notice of the setter
+            prev = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library("hipblas")
+    except Exception:   # a torch build without the switch: whatever library it picks
+        prev = None
+    try:
+        yield
+    finally:
+        if prev is not None:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.backends.cuda.preferred_blas_library(prev)
+
+
+def tall_nt_mm(A, Bt):
+    """A Bt^T for a tall A ([N, K] [M, K]^T, N >> K, M): the dense updates X W and dY W^T of gnn_conv.py:59-68,83.
+    For this shape torch's default (hipBLASLt) picks a 64x32 macro-tile whatever the operand layout; rocBLAS given the
+    second operand K-contiguous runs 233k x 602 x 64 in 0.23 instead of 0.37 ms, 233k x 64 x 41 in 0.028 instead of
+    0.038, dY W^T in 0.029 instead of 0.058 (MI355X, tools/bench_dense_update.py).  Same fp32 arithmetic."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
+        return F.linear(A, Bt)
+    with _rocblas_preferred():
+        return F.linear(A, Bt)
+
+
+def tall_mm(A, B):
+    """A B for a tall A: tall_nt_mm on a K-contiguous copy of the (small) second operand."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
+        return torch.mm(A, B)
+    return tall_nt_mm(A, B.t().contiguous())
+
+
 class TCGNNFunction_SAG(torch.autograd.Function):
     """Pure neighbour aggregation."""
 
@@ -87,11 +128,11 @@ class TCGNNFunction(torch.autograd.Function):
         ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
         ctx.fused = bool(fuse_relu) and hasattr(backend(), "forward_fused")
         if ctx.fused:
-            Y = backend().forward_fused(torch.mm(X, weights), *ctx.meta, relu=True)[0]
+            Y = backend().forward_fused(tall_mm(X, weights), *ctx.meta, relu=True)[0]
             ctx.save_for_backward(X, weights, Y)
             return Y
         ctx.save_for_backward(X, weights)
-        Y = backend().forward(torch.mm(X, weights), *ctx.meta)[0]
+        Y = backend().forward(tall_mm(X, weights), *ctx.meta)[0]
         return torch.relu(Y) if fuse_relu else Y   # (a backend without the fused entry point: plain composition, autograd off here)
 
     @staticmethod
@@ -103,7 +144,7 @@ class TCGNNFunction(torch.autograd.Function):
             X, weights = ctx.saved_tensors
             g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
         # the input features of the first layer need no gradient: skip their N x in_dim product
-        d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
+        d_input = tall_nt_mm(g, weights) if ctx.needs_input_grad[0] else None
         return (d_input, tall_tn_mm(X, g)) + (None,) * 6
 
 
@@ -115,7 +156,7 @@ class TCGNNFunction_GIN(torch.autograd.Function):
         ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
         agg = backend().forward(X, *ctx.meta)[0]
         ctx.save_for_backward(agg, weights)
-        return torch.mm(agg, weights)
+        return tall_mm(agg, weights)
 
     @staticmethod
     def backward(ctx, d_output):
@@ -123,7 +164,7 @@ class TCGNNFunction_GIN(torch.autograd.Function):
         d_weights = tall_tn_mm(agg, d_output.contiguous())
         d_input = None
         if ctx.needs_input_grad[0]:
-            d_input = backend().forward(torch.mm(d_output, weights.t()).contiguous(), *ctx.meta)[0]
+            d_input = backend().forward(tall_nt_mm(d_output.contiguous(), weights), *ctx.meta)[0]
         return (d_input, d_weights) + (None,) * 5
 
 
@@ -137,7 +178,7 @@ class TCGNNFunction_AGNN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, weights, attention_w, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
         meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
-        H = torch.mm(X, weights)
+        H = tall_mm(X, weights)
         b = backend()
         ctx.meta = meta
         ctx.fused = bool(USE_FUSED_AGNN and attention_w.numel() == 1 and hasattr(b, "agnn_fused_forward")
@@ -172,7 +213,7 @@ class TCGNNFunction_AGNN(torch.autograd.Function):
             # dot product <d_att, column_index> per head.  As an [n_heads, E] x [E] matrix-vector product:
             # the 1 x E x 1 GEMM form falls off rocBLAS' fast paths at E ~ 1e8 (30 s per call measured).
             d_attention_w = torch.mv(d_att[None, :].expand(n_heads, -1), column_index.float()).reshape(1, n_heads)
-        d_input = torch.mm(g, weights.t()) if ctx.needs_input_grad[0] else None
+        d_input = tall_nt_mm(g, weights) if ctx.needs_input_grad[0] else None
         d_weights = tall_tn_mm(X, g)
         return (d_input, d_weights, d_attention_w) + (None,) * 5
 
