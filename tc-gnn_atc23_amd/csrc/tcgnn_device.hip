@@ -259,9 +259,25 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
 // absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
 __global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out) {
     uint32_t m = 0;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gsz)
-        if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gate)) & 15) == 0) {   // (scalar loads: 85 us for 2 x 60 MB)
+        const int64_t n4 = n >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const float4* g4 = reinterpret_cast<const float4*>(gate);
+        for (int64_t k = gid; k < n4; k += gsz) {
+            const float4 v = p4[k], gt = g4[k];
+            m = max(m, gt.x > 0.0f ? __float_as_uint(v.x) & 0x7fffffffu : 0u);
+            m = max(m, gt.y > 0.0f ? __float_as_uint(v.y) & 0x7fffffffu : 0u);
+            m = max(m, gt.z > 0.0f ? __float_as_uint(v.z) & 0x7fffffffu : 0u);
+            m = max(m, gt.w > 0.0f ? __float_as_uint(v.w) & 0x7fffffffu : 0u);
+        }
+        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz)
+            if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+    } else {
+        for (int64_t k = gid; k < n; k += gsz)
+            if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     __shared__ uint32_t wmax[4];
