@@ -83,7 +83,8 @@ struct tcgnn_plan {
         uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
     };
     CellStream lds[6];   // (kLdsStreams)
-    bool lds_enabled = false;   // the density test passed (or mode 3 forced it): binary SpMM takes the LDS-resident kernel
+    mutable int8_t lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
+    tcgnn_plan() { for (auto& c : lds_choice) c = -1; }
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
     mutable std::vector<hipEvent_t> ev;
     mutable int ev_used = 0;
@@ -1682,6 +1683,84 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 // Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
 // condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
 static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();   // 0: by width
+// Passes of the LDS-resident kernel over a matrix of dpad columns.  Whole 64-column chunks go as two 32-column passes of the
+// 8-windows-per-wavefront layout (half the workgroups stream each plane pair, 760-row ranges: Reddit D = 64 0.56 vs 0.79 ms),
+// what is left over (1-3 planes) as one pass of the 4-window layout.  TCGNN_LDS_MAXW = 4 / 8 forces one layout for every
+// pass (tests, timing).
+struct LdsPass { int maxw, nt, chunk0, nchunks; };
+static int lds_passes(int dpad, LdsPass (&passes)[2]) {
+    int n = 0;
+    if (g_lds_maxw) {
+        const int cd = lds_chunk_dims(g_lds_maxw);
+        if (dpad / cd) passes[n++] = {g_lds_maxw, cd / 16, 0, dpad / cd};
+        if (dpad % cd) passes[n++] = {g_lds_maxw, (dpad % cd) / 16, dpad / cd, 1};
+    } else {
+        if (dpad / 64) passes[n++] = {kLdsMaxW2, 2, 0, 2 * (dpad / 64)};
+        if (dpad % 64) passes[n++] = {kLdsMaxW, (dpad % 64) / 16, dpad / 64, 1};
+    }
+    return n;
+}
+// workgroups of one pass: enough to hold every window, spread over every CU a pass can have (with 8 windows per wavefront a
+// 64-column chunk takes two passes, hence half the CUs each)
+static int lds_workgroups(const tcgnn_plan* p, int maxw) {
+    const int per_wg = kLdsWaves * maxw;
+    int nwg = (p->nw_eff + per_wg - 1) / per_wg;
+    const int cu_target = maxw == kLdsMaxW2 ? std::max(1, p->num_cus / 2) : p->num_cus;
+    if (nwg < cu_target) nwg = std::max(nwg, std::min(cu_target, (p->nw_eff + kLdsWaves - 1) / kLdsWaves));
+    return nwg;
+}
+
+// Kernel-time models behind the automatic choice between the LDS-resident kernel and the gather walks, microseconds on
+// MI355X (tools/check_lds_threshold.py: nine graphs x two widths; the estimates land within ~15 % of the measured times).
+// The LDS kernel's time follows the column ranges it walks, almost whatever the edge count: per range a fixed part (barrier,
+// DMA issue, metadata; grows with the bytes a range streams) plus ~0.135 us per tile a wavefront multiplies; workgroups
+// beyond one per CU run in further rounds.  The gather walks' time follows the edge count.
+static double lds_estimate_us(const tcgnn_plan* p, int dpad) {
+    LdsPass passes[2];
+    const int np = lds_passes(dpad, passes);
+    const double cols_per_window = 32.0 * (double)p->total_wb / std::max(p->nw_eff, 1);
+    double t = 25.0;
+    for (int i = 0; i < np; ++i) {
+        const int maxw = passes[i].maxw, nt = passes[i].nt;
+        const int rows = lds_stream_buf_rows(lds_stream_of(nt, maxw)) - 8;
+        const double nranges = std::ceil((double)p->Nc / rows);
+        const int nwg = lds_workgroups(p, maxw);
+        const double rounds = std::ceil((double)nwg * passes[i].nchunks / std::max(p->num_cus, 1));
+        const double c = cols_per_window / nranges;                                   // distinct columns of a cell
+        const double tiles_per_cell = c <= 24.0 ? 1.0 - std::exp(-c) : c / 32.0 + 0.5;
+        const double windows_per_wave = (double)p->nw_eff / ((double)nwg * kLdsWaves);
+        static const double fixed4[4] = {0.47, 0.60, 0.89, 1.16};
+        const double a = maxw == kLdsMaxW2 ? 0.80 : fixed4[std::min(nt, 4) - 1];
+        t += rounds * nranges * (a + 0.135 * windows_per_wave * tiles_per_cell);
+    }
+    return t;
+}
+static double gather_estimate_us(const tcgnn_plan* p, int dpad) {
+    const double image = ((double)p->Nc + 1) * x16_pitch(dpad) * 2.0;
+    double ps;   // picoseconds per edge
+    if (image <= (double)kBlockedMinBytes) ps = 4.6 + std::max(0, dpad - 16) * (1.8 / 48.0);        // L2-resident image, per-window walk
+    else if (dpad <= 32) ps = 8.5;
+    else if (dpad <= 64) ps = 8.5 + (dpad - 32) * (1.1 / 32.0);
+    else ps = 9.6 + (dpad - 64) * (6.9 / 64.0);
+    return 20.0 + (double)p->E * ps * 1e-6;
+}
+// automatic mode: the LDS-resident kernel when its estimate is clearly the lower one (decided once per plan and width)
+static bool lds_chosen(const tcgnn_plan* p, int dpad) {
+    if (!g_lds_auto || p->nw_eff <= 0 || p->total_wb <= 0) return false;
+    const int k = dpad / 16;
+    if (k <= 64 && p->lds_choice[k] >= 0) return p->lds_choice[k] != 0;
+    LdsPass passes[2];
+    const int np = lds_passes(dpad, passes);
+    double cells = 0;   // cell-table entries of the streams this width needs (host scan + device memory)
+    for (int i = 0; i < np; ++i) {
+        const int rows = lds_stream_buf_rows(lds_stream_of(passes[i].nt, passes[i].maxw)) - 8;
+        cells += (double)lds_workgroups(p, passes[i].maxw) * kLdsWaves * passes[i].maxw * std::ceil((double)p->Nc / rows);
+    }
+    const bool yes = cells < 2.0e8 && lds_estimate_us(p, dpad) <= 0.9 * gather_estimate_us(p, dpad);
+    if (k <= 64) p->lds_choice[k] = yes ? 1 : 0;
+    return yes;
+}
+
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
@@ -1692,10 +1771,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
     const int nranges = (p->Nc + rows - 1) / rows;
     const int per_wg = kLdsWaves * maxw;
-    int nwg = (nw + per_wg - 1) / per_wg;
-    // spread over every CU; with 8 windows per wavefront a 64-column matrix takes two passes (grid.y), hence half the CUs per pass
-    const int cu_target = maxw == kLdsMaxW2 ? std::max(1, p->num_cus / 2) : p->num_cus;
-    if (nwg < cu_target) nwg = std::max(nwg, std::min(cu_target, (nw + kLdsWaves - 1) / kLdsWaves));
+    const int nwg = lds_workgroups(p, maxw);
     const int64_t ncell = (int64_t)nwg * nranges * per_wg;
     uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
     auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); return rc; };
@@ -1757,8 +1833,26 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
-    const bool lds = !d_val && !d_staged && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && plan->lds_enabled)) &&
-                     (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
+    bool lds = !d_val && !d_staged && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
+               (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
+    LdsPass passes[2]; int npass = 0;
+    if (lds) {
+        // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
+        // one a 64-column matrix uses; a first call with another width synchronises the stream once) - before the staging
+        // pass, which lays the image out for the kernel that will run, and before the timer starts
+        npass = lds_passes(round_up(D, 16), passes);
+        tcgnn_plan* mp = const_cast<tcgnn_plan*>(plan);
+        for (int i = 0; i < npass && lds; ++i) {
+            const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
+            if (plan->lds[slot].nranges > 0) continue;
+            const int b = build_lds_cells(mp, stream, slot);
+            if (b && mode == 3) return b;
+            if (b) {   // automatic mode: the gather walks need no stream (e.g. no memory left for it); remember the answer
+                lds = false;
+                if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0;
+            }
+        }
+    }
     if (d_staged) {   // the caller built the (row-major) fp16 image itself: tcgnn_spmm_staged
         hdr = static_cast<const uint32_t*>(d_staged);
         x16 = reinterpret_cast<const _Float16*>(static_cast<const char*>(d_staged) + kHdrBytes);
@@ -1770,26 +1864,6 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
-        tcgnn_plan* mp = const_cast<tcgnn_plan*>(plan);
-        // Layout by width: whole 64-column chunks go as two 32-column passes of the 8-windows-per-wavefront layout (half the
-        // workgroups stream each plane pair, 760-row ranges: Reddit D = 64 0.70 vs 0.82 ms), what is left over (1-3 planes)
-        // as one pass of the 4-window layout.  TCGNN_LDS_MAXW = 4 / 8 forces one layout for every pass (tests, timing).
-        struct Pass { int maxw, nt, chunk0, nchunks; } passes[2]; int npass = 0;
-        if (g_lds_maxw) {
-            const int cd = lds_chunk_dims(g_lds_maxw);
-            if (dpad / cd) passes[npass++] = {g_lds_maxw, cd / 16, 0, dpad / cd};
-            if (dpad % cd) passes[npass++] = {g_lds_maxw, (dpad % cd) / 16, dpad / cd, 1};
-        } else {
-            if (dpad / 64) passes[npass++] = {kLdsMaxW2, 2, 0, 2 * (dpad / 64)};
-            if (dpad % 64) passes[npass++] = {kLdsMaxW, (dpad % 64) / 16, dpad / 64, 1};
-        }
-        // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
-        // one a 64-column matrix uses; a first call with another width synchronises the stream once) and before the timer
-        // starts, so a first call does not charge the build to the kernel
-        for (int i = 0; i < npass; ++i) {
-            const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
-            if (plan->lds[slot].nranges == 0) { const int b = build_lds_cells(mp, stream, slot); if (b) return b; }
-        }
         KernelTimer timer(plan, stream);
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
@@ -2018,22 +2092,15 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
             p->bytes += b_bp;
         }
     }
-    // Cell stream of the LDS-resident column-range SpMM, for graphs dense enough that a feature row streamed into a
-    // CU's LDS is used more than once by the 64 windows resident there (Reddit: 2.2 uses; ogbn-products: 0.02) and
-    // big enough that the gather walks would leave the L2 (tcgnn_lds_spmm.inc).  TCGNN_LDS_AUTO=0 disables it.
-    if (g_lds_auto && nw >= 4 * p->num_cus && (size_t)num_cols * 128 >= kBlockedMinBytes) {
-        // windows a workgroup will actually hold: the stream spreads them over every CU (build_lds_cells), so a graph with few
-        // windows gives each CU only a handful to amortise its pass over X (N = 60 k, 20 M edges: 16 per workgroup - the LDS
-        // kernel then ran 0.163 ms against 0.128 ms for the per-window walk)
-        const int per_wg = kLdsWaves * kLdsMaxW;
-        int lnwg = (nw + per_wg - 1) / per_wg;
-        if (lnwg < p->num_cus) lnwg = std::max(lnwg, std::min(p->num_cus, (nw + kLdsWaves - 1) / kLdsWaves));
-        const double wpw = (double)nw / std::max(lnwg, 1);
-        const double uses = (double)num_edges * (wpw * kWinRows) / ((double)std::max(num_rows, 1) * (double)std::max(num_cols, 1));
-        const double cells = (double)nw * ((double)num_cols / (lds_stream_buf_rows(0) - 8) + 1.0);
-        if (uses >= 1.5 && cells < 1.0e9) {
-            p->lds_enabled = true;
-            const int rc = build_lds_cells(p, stream, g_lds_maxw == kLdsMaxW ? 0 : lds_stream_of(2, kLdsMaxW2));   // what a 64-column matrix takes
+    // Cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc) when the time models pick that kernel for a
+    // 64-column matrix: built now rather than inside the first call.  Other widths decide, and build, at their first call.
+    // TCGNN_LDS_AUTO=0 disables the automatic choice.
+    if (lds_chosen(p, 64)) {
+        LdsPass passes[2];
+        const int np = lds_passes(64, passes);
+        for (int i = 0; i < np; ++i) {
+            const int rc = build_lds_cells(p, stream, lds_stream_of(passes[i].nt, passes[i].maxw));
+            if (rc == TCGNN_ERR_OOM) { p->lds_choice[4] = 0; break; }   // (the gather walks need no stream)
             if (rc) return bail(rc);
         }
     }
