@@ -18,8 +18,9 @@ through ef into H; both are reproduced because the golden fixtures captured from
 The operators come from `backend()`: the TCGNN module of this package (HIP kernels).  Tests on a
 machine without a GPU may install another object with the same three functions via set_backend().
 """
-import contextlib
 import math
+import os
+import sys
 import time
 import warnings
 
@@ -47,6 +48,8 @@ def backend():
 
 _SPLIT_ROWS = 1 << 15   # below this a plain mm is fine
 _SPLIT_PARTS = 64
+_ROCBLAS_MIN_K = 32   # inner dimension from which rocBLAS' K-contiguous form wins (tools/bench_tall_gemm_grid.py: 1.1-2.4x from K = 41 up,
+                       # 0.2-0.9x at K = 16)
 
 
 def tall_tn_mm(A, B):
@@ -65,40 +68,59 @@ def tall_tn_mm(A, B):
     return out
 
 
-@contextlib.contextmanager
-def _rocblas_preferred():
-    """torch's BLAS preference set to rocBLAS for the duration (restored on exit; host-side state, safe under graph capture)."""
-    prev = None
+_blas_switch = None   # (set, rocblas, default) once probed; False: this torch build has no such switch
+
+
+def _probe_blas_switch():
+    global _blas_switch
     try:
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")   # "experimental feature" notice of the setter
-            prev = torch.backends.cuda.preferred_blas_library()
-            torch.backends.cuda.preferred_blas_library("hipblas")
-    except Exception:   # a torch build without the switch: whatever library it picks
-        prev = None
-    try:
-        yield
-    finally:
-        if prev is not None:
+        # (the setter's one-off "experimental feature" notice is written to fd 2 by the C++ logger: silenced for the probe)
+        sys.stderr.flush()
+        saved, null = os.dup(2), os.open(os.devnull, os.O_WRONLY)
+        try:
+            os.dup2(null, 2)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                torch.backends.cuda.preferred_blas_library(prev)
+                default = torch.backends.cuda.preferred_blas_library()
+                rocblas = torch.backends.cuda.preferred_blas_library("hipblas")
+                torch.backends.cuda.preferred_blas_library(default)
+        finally:
+            os.dup2(saved, 2); os.close(saved); os.close(null)
+        setter = getattr(torch._C, "_set_blas_preferred_backend", None) or torch.backends.cuda.preferred_blas_library
+        _blas_switch = (setter, rocblas, default)
+    except Exception:
+        _blas_switch = False
+
+
+def _linear_rocblas(A, Bt):
+    """F.linear with torch's BLAS preference set to rocBLAS for the call (host-side state, restored on exit; the epochs of
+    small graphs are launch-bound, so the switch is two plain calls, not a context manager)."""
+    if _blas_switch is None:
+        _probe_blas_switch()
+    if not _blas_switch:
+        return F.linear(A, Bt)
+    setter, rocblas, default = _blas_switch
+    setter(rocblas)
+    try:
+        return F.linear(A, Bt)
+    finally:
+        setter(default)
 
 
 def tall_nt_mm(A, Bt):
     """A Bt^T for a tall A ([N, K] [M, K]^T, N >> K, M): the dense updates X W and dY W^T of gnn_conv.py:59-68,83.
     For this shape torch's default (hipBLASLt) picks a 64x32 macro-tile whatever the operand layout; rocBLAS given the
     second operand K-contiguous runs 233k x 602 x 64 in 0.23 instead of 0.37 ms, 233k x 64 x 41 in 0.028 instead of
-    0.038, dY W^T in 0.029 instead of 0.058 (MI355X, tools/bench_dense_update.py).  Same fp32 arithmetic."""
-    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
+    0.038, dY W^T in 0.029 instead of 0.058 (MI355X, tools/bench_dense_update.py).  Not for short inner dimensions (hidden = 16:
+    rocBLAS is 3-5x slower there).  Same fp32 arithmetic."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS or A.shape[1] < _ROCBLAS_MIN_K:
         return F.linear(A, Bt)
-    with _rocblas_preferred():
-        return F.linear(A, Bt)
+    return _linear_rocblas(A, Bt)
 
 
 def tall_mm(A, B):
     """A B for a tall A: tall_nt_mm on a K-contiguous copy of the (small) second operand."""
-    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS or A.shape[1] < _ROCBLAS_MIN_K:
         return torch.mm(A, B)
     return tall_nt_mm(A, B.t().contiguous())
 
