@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""SDDMM and the fused AGNN forward on the Reddit shape: automatic walk against the per-window (1) and range-major (2) walks."""
 import os, sys
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")): sys.path.insert(0, p)
 import numpy as np, torch
 import TCGNN, tcgnn_graph as G, tcgnn_capi as c
