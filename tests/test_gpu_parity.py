@@ -587,7 +587,8 @@ def test_full_size_reddit_shape_properties(dev, T):
     # this graph is dense enough for the LDS-resident column-range kernel (the automatic choice above): the range-blocked
     # gather walk and the per-window walk must give the same sums (fp32 accumulation order differs: ~1e-5 of the scale)
     import tcgnn_capi as c
-    assert T.plan_info(*meta)["lds_ranges"] in ((n + 503) // 504, (n + 759) // 760)   # 4- or 8-window layout (TCGNN_LDS_MAXW)
+    if os.environ.get("TCGNN_LDS_AUTO", "1") != "0":   # (the variable switches the automatic choice off)
+        assert T.plan_info(*meta)["lds_ranges"] in ((n + 503) // 504, (n + 759) // 760)   # 4- or 8-window layout (TCGNN_LDS_MAXW)
     try:
         for mode in (1, 2):
             c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
