@@ -501,6 +501,27 @@ def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
         assert abs(long_g["final_loss"] - long_e["final_loss"]) <= 0.5 * max(long_e["final_loss"], short["final_loss"]), (model, long_g, long_e)
 
 
+@pytest.mark.parametrize("shape", [(40000, 64, 41), (70001, 96, 16), (33000, 602, 64), (40000, 16, 64)])
+def test_tall_dense_updates_match_a_float64_product(dev, shape):
+    """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm through rocBLAS from inner dimension 32 up, tall_tn_mm as a
+    64-slab batched product) against float64: fp32 GEMM accuracy, 1e-5 of the row-times-column norm bound; the library
+    preference they switch for the call is restored afterwards."""
+    import tcgnn_layers as L
+    n, k, m = shape
+    g = torch.Generator(device=dev).manual_seed(n + k)
+    A = torch.randn(n, k, device=dev, generator=g); W = torch.randn(k, m, device=dev, generator=g); G = torch.randn(n, m, device=dev, generator=g)
+    before = torch.backends.cuda.preferred_blas_library()
+    got = {"A W": L.tall_mm(A, W), "G W^T": L.tall_nt_mm(G, W), "A^T G": L.tall_tn_mm(A, G)}
+    assert torch.backends.cuda.preferred_blas_library() == before
+    want = {"A W": A.double() @ W.double(), "G W^T": G.double() @ W.double().t(), "A^T G": A.double().t() @ G.double()}
+    bound = {"A W": A.double().norm(dim=1)[:, None] * W.double().norm(dim=0)[None, :],
+             "G W^T": G.double().norm(dim=1)[:, None] * W.double().norm(dim=1)[None, :],
+             "A^T G": A.double().norm(dim=0)[:, None] * G.double().norm(dim=0)[None, :]}
+    for name in got:
+        err = ((got[name].double() - want[name]).abs() / bound[name]).max().item()
+        assert err < 1e-5, (name, shape, err)
+
+
 def test_range_robustness_beyond_fp16(dev, T):
     """Values far outside fp16's range (the reference's TF32 has fp32's exponent) survive the
     per-call power-of-two scaling."""
