@@ -1668,7 +1668,10 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
-        if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
+        if (vec && D % 16 == 0 && (!d_gate || (reinterpret_cast<uintptr_t>(d_gate) & 15) == 0)) {
+            const int64_t threads = ((int64_t)plan->Nc + 1) * (D / 4);
+            hipLaunchKernelGGL(convert_planar_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_X, plan->Nc, D, x16, hdr, d_gate);
+        } else if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
         else if ((size_t)D * 64 * sizeof(float) <= 48 * 1024)
             hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
                                d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
