@@ -1175,9 +1175,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
                 const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
                 if ((uint32_t)lane < c_r) {
-#ifndef TCGNN_EXPERIMENT_NO_EF_STORE
                     *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
-#endif
                     const uint32_t ab = vals[r] & 0x7fffffffu;           // max |ef| for the backward call's scale
                     emax = ab > emax ? ab : emax;
                 }
