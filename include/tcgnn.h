@@ -68,7 +68,8 @@ typedef struct tcgnn_plan_info {
     int32_t canonical;       /* 1 if every CSR row is strictly increasing (scipy canonical form) */
     int32_t waves_per_window;/* workgroup shape the launcher picked (1 or 4 wavefronts) */
     int32_t column_buckets;  /* > 0: the plan carries the bucket table of the range-blocked SpMM walk */
-    int32_t lds_ranges;      /* > 0: the plan carries the cell stream of the LDS-resident column-range SpMM */
+    int32_t lds_ranges;      /* > 0: the plan carries a cell stream of the LDS-resident column-range SpMM (column ranges of the
+                              * finest stream built so far; streams are per pass width and built on first use) */
 } tcgnn_plan_info;
 
 int tcgnn_abi_version(void);
@@ -140,8 +141,10 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
 int tcgnn_plan_destroy(tcgnn_plan* plan);
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
 
-/* Tuning / test aid: which SpMM walk tcgnn_spmm and tcgnn_spmm_val use.  0 = automatic (default;
- * range-blocked when the fp16 image of X exceeds the L2 and the windows are long), 1 = always the
+/* Tuning / test aid: which SpMM walk tcgnn_spmm and tcgnn_spmm_val use.  0 = automatic (default: per plan
+ * and feature width, the LDS-resident kernel or the gather walks by their time models - DESIGN.md "Which walk
+ * runs"; among the gather walks range-blocked when the fp16 image of X exceeds the L2 and the windows are long;
+ * TCGNN_LDS_AUTO=0 in the environment keeps the automatic mode off the LDS-resident kernel), 1 = always the
  * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table, 3 = the
  * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
  * plan was created without one), 4 = the single-launch fp32-MFMA kernel small graphs take automatically
