@@ -2,6 +2,8 @@
 """One rank's share of bench.py's N-GPU weak-scaling workload, on ONE GPU and without a process group: rank 0's rows of the
 N x 232 965-node graph (114.6 M edges, columns over all N blocks), its sharded plan and the local SpMM on a replicated X.
 Shows which kernel the shard takes and what it costs per GPU at N = 1, 2, 4, 8 before the driver runs the real thing.
+TCGNN_SHARD_LOCALITY=f (0..1) puts that fraction of the edges inside the rank's own column block (a partitioned graph; the
+driver's workload is f = 0: columns uniform over all blocks).
 usage: bench_shard_shape.py [N ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +19,10 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     g = torch.Generator(device=dev).manual_seed(0)
     rows = torch.randint(0, n0, (nnz0,), device=dev, generator=g)
     cols = torch.randint(0, n_global, (nnz0,), device=dev, generator=g)
+    f_local = float(os.environ.get("TCGNN_SHARD_LOCALITY", "0"))
+    if f_local > 0:   # rank 0's own block is columns [0, n0)
+        own = torch.rand(nnz0, device=dev, generator=g) < f_local
+        cols = torch.where(own, torch.randint(0, n0, (nnz0,), device=dev, generator=g), cols)
     keys = torch.unique(rows.long() * n_global + cols.long())
     rows, cols = keys // n_global, keys % n_global
     counts = torch.bincount(rows, minlength=n0)
