@@ -47,22 +47,24 @@ def backend():
 
 
 _SPLIT_ROWS = 1 << 15   # below this a plain mm is fine
-_SPLIT_PARTS = 64
+_SPLIT_PARTS = 256
 _ROCBLAS_MIN_K = 32   # inner dimension from which rocBLAS' K-contiguous form wins (tools/bench_tall_gemm_grid.py: 1.1-2.4x from K = 41 up,
                        # 0.2-0.9x at K = 16)
 
 
 def tall_tn_mm(A, B):
     """A^T B for tall operands ([N, K]^T [N, M], N >> K, M): the weight-gradient products of gnn_conv.py:84,111,147.
-    rocBLAS runs this shape as one long reduction per output tile (0.59 ms for 233k x 602 x 64 on MI355X);
-    cutting N into 64 slabs (one batched GEMM + a fixed-order sum, so still deterministic) takes 0.26 ms,
-    and 0.055 instead of 0.46 ms for 233k x 64 x 41."""
+    The BLAS libraries run this shape as one long reduction per output tile (0.59 ms for 233k x 602 x 64 on MI355X, 1.4 ms in
+    rocBLAS); cutting N into slabs (one batched GEMM + a fixed-order sum, so still deterministic) takes 0.18 ms with 256
+    slabs in rocBLAS (0.24 with 64 in hipBLASLt, torch's default), and 0.06 instead of 0.46 ms for 233k x 64 x 41
+    (tools/bench_weight_grad.py)."""
     n = A.shape[0]
     if n < _SPLIT_ROWS:
         return torch.mm(A.t(), B)
     m = n // _SPLIT_PARTS * _SPLIT_PARTS
-    out = torch.bmm(A[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1).transpose(1, 2),
-                    B[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1)).sum(0)
+    a3 = A[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1).transpose(1, 2)
+    b3 = B[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1)
+    out = (_with_rocblas(torch.bmm, a3, b3) if A.is_cuda else torch.bmm(a3, b3)).sum(0)
     if m < n:
         out = out + torch.mm(A[m:].t(), B[m:])
     return out
@@ -92,17 +94,17 @@ def _probe_blas_switch():
         _blas_switch = False
 
 
-def _linear_rocblas(A, Bt):
-    """F.linear with torch's BLAS preference set to rocBLAS for the call (host-side state, restored on exit; the epochs of
+def _with_rocblas(fn, *args):
+    """fn(*args) with torch's BLAS preference set to rocBLAS for the call (host-side state, restored on exit; the epochs of
     small graphs are launch-bound, so the switch is two plain calls, not a context manager)."""
     if _blas_switch is None:
         _probe_blas_switch()
     if not _blas_switch:
-        return F.linear(A, Bt)
+        return fn(*args)
     setter, rocblas, default = _blas_switch
     setter(rocblas)
     try:
-        return F.linear(A, Bt)
+        return fn(*args)
     finally:
         setter(default)
 
@@ -115,7 +117,7 @@ def tall_nt_mm(A, Bt):
     rocBLAS is 3-5x slower there).  Same fp32 arithmetic."""
     if not A.is_cuda or A.shape[0] < _SPLIT_ROWS or A.shape[1] < _ROCBLAS_MIN_K:
         return F.linear(A, Bt)
-    return _linear_rocblas(A, Bt)
+    return _with_rocblas(F.linear, A, Bt)
 
 
 def tall_mm(A, B):
