@@ -1846,6 +1846,14 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         for (int i = 0; i < npass && lds; ++i) {
             const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
             if (plan->lds[slot].nranges > 0) continue;
+            // a stream that is being captured into a HIP graph cannot allocate or synchronise: this call takes the gather walks
+            // (nothing is remembered: the next call outside a capture builds the cell stream)
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+                if (mode == 3) return fail(TCGNN_ERR_INVALID_ARG, "LDS-resident SpMM: the cell stream of this width has to be built before the call is captured into a graph");
+                lds = false;
+                break;
+            }
             const int b = build_lds_cells(mp, stream, slot);
             if (b && mode == 3) return b;
             if (b) {   // automatic mode: the gather walks need no stream (e.g. no memory left for it); remember the answer

@@ -522,6 +522,47 @@ def test_tall_dense_updates_match_a_float64_product(dev, shape):
         assert err < 1e-5, (name, shape, err)
 
 
+def test_first_call_of_a_width_inside_a_graph_capture_takes_a_gather_walk(dev, T):
+    """A width whose cell stream does not exist yet cannot have it built while the stream is being captured (the build
+    allocates and synchronises): the captured call runs a gather walk and leaves the plan as it was, the next eager call
+    builds the stream, and both give the sums of the per-window walk.  (N = 60 k / 20 M edges: the LDS-resident kernel is
+    the automatic choice at 16 columns, and plan creation only builds what a 64-column matrix needs.)"""
+    import tcgnn_capi as c
+    import tcgnn_graph as G
+    if os.environ.get("TCGNN_SPMM_MODE", "0") == "3":
+        pytest.skip("with the LDS-resident walk forced, capturing an unbuilt width is an error by design")
+    n = 60000
+    rp, col = G.synthetic_csr(n, 20_000_000, seed=5, device=dev)
+    E = col.numel(); nw = (n + 15) // 16
+    bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+    T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+    meta = (rp, col, bp, e2c, e2r)
+    X = torch.randn(n, 16, device=dev)
+    bytes_created = T.plan_info(*meta)["plan_bytes"]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        Yw = T.forward(torch.randn(n, 64, device=dev), *meta)[0]   # warms torch's allocator on the capture stream (another width)
+        bytes_before = T.plan_info(*meta)["plan_bytes"]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            Yg = T.forward(X, *meta)[0]
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay(); torch.cuda.synchronize()
+    assert T.plan_info(*meta)["plan_bytes"] == bytes_before >= bytes_created      # nothing was built under capture
+    Ye = T.forward(X, *meta)[0]
+    if os.environ.get("TCGNN_LDS_AUTO", "1") != "0" and os.environ.get("TCGNN_SPMM_MODE", "0") == "0":
+        assert T.plan_info(*meta)["plan_bytes"] > bytes_before                    # the eager call built the 16-column stream
+    c.check(c.lib.tcgnn_set_spmm_mode(1), "mode")
+    try:
+        Y1 = T.forward(X, *meta)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    scale = float(X.abs().max()) * float((rp[1:] - rp[:-1]).max()) ** 0.5
+    assert float((Yg - Y1).abs().max()) < 1e-4 * scale and float((Ye - Y1).abs().max()) < 1e-4 * scale
+    del Yw
+
+
 def test_range_robustness_beyond_fp16(dev, T):
     """Values far outside fp16's range (the reference's TF32 has fp32's exponent) survive the
     per-call power-of-two scaling."""
