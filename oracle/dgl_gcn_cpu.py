@@ -14,7 +14,6 @@ A[r, c] = 1 for CSR entry (r, c): row r aggregates from its columns (in-degree =
 No reference test pins DGL's results: PARITY UNPINNED - this file is only ever timed, and checked against a dense-matrix
 evaluation of the same formula (tests/test_dgl_cpu_baseline.py).
 """
-import math
 import time
 
 import numpy as np

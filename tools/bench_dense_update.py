@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times formulations of the dense update X[N,in] @ W[in,out] of the first GCN layer (Reddit: 232965 x 602 x 64, fp32)."""
-import os, sys, time
+import os, sys
 import torch
 import torch.nn.functional as F
 dev = torch.device("cuda:0")

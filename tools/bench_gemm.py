@@ -1,5 +1,5 @@
 """Times the dense updates around the SpMM at the Reddit GCN shapes (torch.mm, fp32) - is the BLAS choice sane?"""
-import sys, torch
+import torch
 N = 232965
 def t(fn, reps=20):
     for _ in range(3): fn()

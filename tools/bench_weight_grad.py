@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """X^T G for tall operands (the weight gradients): slab counts of the batched split-K form, under both BLAS libraries."""
-import os, sys, warnings
+import warnings
 import torch
 dev = torch.device("cuda:0")
 warnings.simplefilter("ignore")
