@@ -2,7 +2,7 @@
 """CHECKER-SIDE UTILITY (lives under oracle/; nothing in the product imports it).  Quick on-GPU diagnostics: max errors of the three kernels against the oracle over a grid of
 graph shapes and feature widths, plus first timings.  Not a test (tests/test_gpu_parity.py is);
 prints numbers so a failure can be localised from one gpurun call."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
