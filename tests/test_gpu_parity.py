@@ -563,6 +563,28 @@ def test_first_call_of_a_width_inside_a_graph_capture_takes_a_gather_walk(dev, T
     del Yw
 
 
+def test_automatic_walk_follows_the_time_models(dev, T):
+    """The automatic mode picks the LDS-resident kernel per plan and width from its time models (DESIGN.md "Which walk
+    runs"): a 60 k-node graph with 20 M edges takes it at 64 columns (cell stream built at plan creation); the Reddit node
+    count at 15 M edges does not, at either width (its cells run empty: the range walk costs more than gathering 15 M rows)."""
+    import tcgnn_graph as G
+    if os.environ.get("TCGNN_LDS_AUTO", "1") == "0" or os.environ.get("TCGNN_SPMM_MODE", "0") != "0" or os.environ.get("TCGNN_LDS_MAXW"):
+        pytest.skip("the automatic choice is overridden by the environment")
+    for n, nnz, expect_lds in ((60000, 20_000_000, True), (232965, 15_000_000, False)):
+        rp, col = G.synthetic_csr(n, nnz, seed=9, device=dev)
+        E = col.numel(); nw = (n + 15) // 16
+        bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+        T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+        meta = (rp, col, bp, e2c, e2r)
+        deg = (rp[1:] - rp[:-1]).float()
+        for D in (64, 16):
+            Y = T.forward(torch.ones(n, D, device=dev), *meta)[0]
+            assert torch.equal(Y, deg[:, None].expand(-1, D))
+        assert (T.plan_info(*meta)["lds_ranges"] > 0) == expect_lds, (n, nnz, T.plan_info(*meta))
+        del rp, col, bp, e2c, e2r, meta, Y
+        torch.cuda.empty_cache()
+
+
 def test_range_robustness_beyond_fp16(dev, T):
     """Values far outside fp16's range (the reference's TF32 has fp32's exponent) survive the
     per-call power-of-two scaling."""
