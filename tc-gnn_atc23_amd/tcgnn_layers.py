@@ -46,31 +46,18 @@ def backend():
     return _backend
 
 
-_SPLIT_ROWS = 1 << 15   # below this a plain mm is fine
-_SPLIT_PARTS = 256
-_ROCBLAS_MIN_K = 32   # inner dimension from which rocBLAS' K-contiguous form wins (tools/bench_tall_gemm_grid.py: 1.1-2.4x from K = 41 up,
-                       # 0.2-0.9x at K = 16)
+_SPLIT_ROWS = 1 << 15   # below this the plain products are fine
 
-
-def tall_tn_mm(A, B):
-    """A^T B for tall operands ([N, K]^T [N, M], N >> K, M): the weight-gradient products of gnn_conv.py:84,111,147.
-    The BLAS libraries run this shape as one long reduction per output tile (0.59 ms for 233k x 602 x 64 on MI355X, 1.4 ms in
-    rocBLAS); cutting N into slabs (one batched GEMM + a fixed-order sum, so still deterministic) takes 0.18 ms with 256
-    slabs in rocBLAS (0.24 with 64 in hipBLASLt, torch's default), and 0.06 instead of 0.46 ms for 233k x 64 x 41
-    (tools/bench_weight_grad.py)."""
-    n = A.shape[0]
-    if n < _SPLIT_ROWS:
-        return torch.mm(A.t(), B)
-    m = n // _SPLIT_PARTS * _SPLIT_PARTS
-    a3 = A[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1).transpose(1, 2)
-    b3 = B[:m].reshape(_SPLIT_PARTS, m // _SPLIT_PARTS, -1)
-    out = (_with_rocblas(torch.bmm, a3, b3) if A.is_cuda else torch.bmm(a3, b3)).sum(0)
-    if m < n:
-        out = out + torch.mm(A[m:].t(), B[m:])
-    return out
-
-
+# The layers' own GEMMs are tall and thin (233k x 602 x 64, 2.4M x 100 x 128 ...) and neither BLAS library's heuristics are
+# reliable there: on MI355X rocBLAS with the small operand K-contiguous runs Reddit's X W in 0.23 ms against hipBLASLt's
+# 0.37 but loses 0.99 : 0.93 at the ogbn-products shape; the weight gradient as a 256-slab batched product takes 0.18 ms
+# in rocBLAS at Reddit's shape and 1.35 against hipBLASLt's 0.67 at products'; K = 16 is 3-5x slower in rocBLAS
+# (tools/bench_tall_gemm_grid.py, bench_weight_grad.py, bench_gemm_products_shape.py).  So each (product, shape) is MEASURED
+# the first time it is met - every candidate once after a warm-up call, HIP events - and the winner kept for the process.
+# All candidates are fp32 products of the same operands (they differ in summation order only).  A first meeting inside a
+# graph capture (no synchronisation allowed) takes the first candidate and decides nothing.
 _blas_switch = None   # (set, rocblas, default) once probed; False: this torch build has no such switch
+_tuned = {}           # (product, N, K, M, dtype) -> index of the winning candidate
 
 
 def _probe_blas_switch():
@@ -94,6 +81,10 @@ def _probe_blas_switch():
         _blas_switch = False
 
 
+if torch.cuda.is_available():
+    _probe_blas_switch()   # here, not inside an autograd Function: C++ warnings raised there surface after the filter is gone
+
+
 def _with_rocblas(fn, *args):
     """fn(*args) with torch's BLAS preference set to rocBLAS for the call (host-side state, restored on exit; the epochs of
     small graphs are launch-bound, so the switch is two plain calls, not a context manager)."""
@@ -109,22 +100,71 @@ def _with_rocblas(fn, *args):
         setter(default)
 
 
+def _slabs_tn(A, B, parts, rocblas):
+    """A^T B as `parts` slab products (one batched GEMM) and a fixed-order sum - deterministic for a given `parts`."""
+    n = A.shape[0]
+    m = n // parts * parts
+    a3 = A[:m].reshape(parts, m // parts, -1).transpose(1, 2)
+    b3 = B[:m].reshape(parts, m // parts, -1)
+    out = (_with_rocblas(torch.bmm, a3, b3) if rocblas else torch.bmm(a3, b3)).sum(0)
+    if m < n:
+        out = out + torch.mm(A[m:].t(), B[m:])
+    return out
+
+
+_CANDIDATES = {
+    # A [N, K] @ W [K, M]
+    "mm": (lambda A, W: torch.mm(A, W),
+           lambda A, W: _with_rocblas(F.linear, A, W.t().contiguous())),
+    # A [N, K] @ Bt [M, K]^T
+    "nt": (lambda A, Bt: F.linear(A, Bt),
+           lambda A, Bt: _with_rocblas(F.linear, A, Bt)),
+    # A [N, K]^T @ B [N, M]
+    "tn": (lambda A, B: _slabs_tn(A, B, 64, False),
+           lambda A, B: _slabs_tn(A, B, 256, False),
+           lambda A, B: _slabs_tn(A, B, 128, False),
+           lambda A, B: _slabs_tn(A, B, 256, True)),
+}
+
+
+def _tall(product, A, B):
+    cands = _CANDIDATES[product]
+    key = (product, A.shape[0], A.shape[1], B.shape[0] if product == "nt" else B.shape[1], A.dtype)
+    best = _tuned.get(key)
+    if best is None:
+        if torch.cuda.is_current_stream_capturing():
+            return cands[0](A, B)
+        times = []
+        for fn in cands:
+            fn(A, B)   # warm-up (library initialisation, workspace)
+            t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            t0.record(); fn(A, B); t1.record(); fn(A, B); t2.record(); t2.synchronize()
+            times.append(min(t0.elapsed_time(t1), t1.elapsed_time(t2)))
+        best = _tuned[key] = min(range(len(cands)), key=times.__getitem__)
+    return cands[best](A, B)
+
+
+def tall_tn_mm(A, B):
+    """A^T B for tall operands ([N, K]^T [N, M], N >> K, M): the weight-gradient products of gnn_conv.py:84,111,147.
+    The BLAS libraries run this shape as one long reduction per output tile (0.59 ms for 233k x 602 x 64 on MI355X); cut into
+    slabs it takes 0.18-0.24 ms, which slab count and library being measured per shape (see above)."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
+        return torch.mm(A.t(), B)
+    return _tall("tn", A, B)
+
+
 def tall_nt_mm(A, Bt):
-    """A Bt^T for a tall A ([N, K] [M, K]^T, N >> K, M): the dense updates X W and dY W^T of gnn_conv.py:59-68,83.
-    For this shape torch's default (hipBLASLt) picks a 64x32 macro-tile whatever the operand layout; rocBLAS given the
-    second operand K-contiguous runs 233k x 602 x 64 in 0.23 instead of 0.37 ms, 233k x 64 x 41 in 0.028 instead of
-    0.038, dY W^T in 0.029 instead of 0.058 (MI355X, tools/bench_dense_update.py).  Not for short inner dimensions (hidden = 16:
-    rocBLAS is 3-5x slower there).  Same fp32 arithmetic."""
-    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS or A.shape[1] < _ROCBLAS_MIN_K:
+    """A Bt^T for a tall A ([N, K] [M, K]^T, N >> K, M): dY W^T of gnn_conv.py:83; library measured per shape."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
         return F.linear(A, Bt)
-    return _with_rocblas(F.linear, A, Bt)
+    return _tall("nt", A, Bt)
 
 
 def tall_mm(A, B):
-    """A B for a tall A: tall_nt_mm on a K-contiguous copy of the (small) second operand."""
-    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS or A.shape[1] < _ROCBLAS_MIN_K:
+    """A B for a tall A ([N, K] [K, M]): the dense updates X W of gnn_conv.py:59-68; library and layout measured per shape."""
+    if not A.is_cuda or A.shape[0] < _SPLIT_ROWS:
         return torch.mm(A, B)
-    return tall_nt_mm(A, B.t().contiguous())
+    return _tall("mm", A, B)
 
 
 class TCGNNFunction_SAG(torch.autograd.Function):

@@ -503,9 +503,9 @@ def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
 
 @pytest.mark.parametrize("shape", [(40000, 64, 41), (70001, 96, 16), (33000, 602, 64), (40000, 16, 64)])
 def test_tall_dense_updates_match_a_float64_product(dev, shape):
-    """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm through rocBLAS from inner dimension 32 up, tall_tn_mm as a
-    64-slab batched product) against float64: fp32 GEMM accuracy, 1e-5 of the row-times-column norm bound; the library
-    preference they switch for the call is restored afterwards."""
+    """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm / tall_tn_mm: library, layout and slab count measured per
+    shape on first use) against float64: fp32 GEMM accuracy, 1e-5 of the row-times-column norm bound; the library
+    preference they may switch for a call is restored afterwards, and a second call returns the same bits."""
     import tcgnn_layers as L
     n, k, m = shape
     g = torch.Generator(device=dev).manual_seed(n + k)
@@ -513,6 +513,7 @@ def test_tall_dense_updates_match_a_float64_product(dev, shape):
     before = torch.backends.cuda.preferred_blas_library()
     got = {"A W": L.tall_mm(A, W), "G W^T": L.tall_nt_mm(G, W), "A^T G": L.tall_tn_mm(A, G)}
     assert torch.backends.cuda.preferred_blas_library() == before
+    assert torch.equal(got["A W"], L.tall_mm(A, W)) and torch.equal(got["A^T G"], L.tall_tn_mm(A, G))   # the choice is kept
     want = {"A W": A.double() @ W.double(), "G W^T": G.double() @ W.double().t(), "A^T G": A.double().t() @ G.double()}
     bound = {"A W": A.double().norm(dim=1)[:, None] * W.double().norm(dim=0)[None, :],
              "G W^T": G.double().norm(dim=1)[:, None] * W.double().norm(dim=1)[None, :],
