@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -1743,6 +1744,9 @@ static double gather_estimate_us(const tcgnn_plan* p, int dpad) {
     else if (dpad <= 32) ps = 8.5;
     else if (dpad <= 64) ps = 8.5 + (dpad - 32) * (1.1 / 32.0);
     else ps = 9.6 + (dpad - 64) * (6.9 / 64.0);
+    // the gathered image leaves first the L2s, then the Infinity Cache (row shards of the multi-GPU workload: 60 / 119 / 239 MB
+    // -> 10.0 / 12.4 / 14.7 ps per edge at 64 columns)
+    if (image > 45.0e6) ps *= std::pow(image / 45.0e6, 0.3);
     return 20.0 + (double)p->E * ps * 1e-6;
 }
 // automatic mode: the LDS-resident kernel when its estimate is clearly the lower one (decided once per plan and width)
@@ -1757,7 +1761,7 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
         const int rows = lds_stream_buf_rows(lds_stream_of(passes[i].nt, passes[i].maxw)) - 8;
         cells += (double)lds_workgroups(p, passes[i].maxw) * kLdsWaves * passes[i].maxw * std::ceil((double)p->Nc / rows);
     }
-    const bool yes = cells < 2.0e8 && lds_estimate_us(p, dpad) <= 0.9 * gather_estimate_us(p, dpad);
+    const bool yes = cells < 2.0e8 && lds_estimate_us(p, dpad) <= 0.95 * gather_estimate_us(p, dpad);
     if (k <= 64) p->lds_choice[k] = yes ? 1 : 0;
     return yes;
 }
