@@ -167,6 +167,28 @@ def tall_mm(A, B):
     return _tall("mm", A, B)
 
 
+class _DenseUpdate(torch.autograd.Function):
+    """X W with the tall products above in both directions (autograd's own backward of torch.mm takes the plain X^T G)."""
+
+    @staticmethod
+    def forward(ctx, X, W):
+        ctx.save_for_backward(X, W)
+        return tall_mm(X, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W = ctx.saved_tensors
+        g = g.contiguous()
+        d_x = tall_nt_mm(g, W) if ctx.needs_input_grad[0] else None
+        d_w = tall_tn_mm(X, g) if ctx.needs_input_grad[1] else None
+        return d_x, d_w
+
+
+def dense_update(X, W):
+    """Differentiable X W for callers outside the layer Functions below (tcgnn_shard.ShardedGCN)."""
+    return _DenseUpdate.apply(X, W)
+
+
 class TCGNNFunction_SAG(torch.autograd.Function):
     """Pure neighbour aggregation."""
 

@@ -25,6 +25,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from tcgnn_layers import dense_update
+
 BLK_H = 16
 
 
@@ -301,7 +303,7 @@ class ShardedGCN(torch.nn.Module):
         h = x_local
         last = len(self.weights) - 1
         for k, w in enumerate(self.weights):
-            h = shard.aggregate(torch.mm(h, w))
+            h = shard.aggregate(dense_update(h, w))
             if k != last:
                 h = torch.relu(h)
                 if k == 0 and self.dropout > 0:
