@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Three other dense shapes (N = 100 k / 60 k / 400 k), D = 64 and 16: the automatic walk against the forced per-window (1) and
+range-blocked (2) walks for SpMM, SDDMM and the fused AGNN forward, with the differences between their results."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")): sys.path.insert(0, p)
