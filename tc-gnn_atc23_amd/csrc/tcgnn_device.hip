@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -77,18 +78,20 @@ struct tcgnn_plan {
     size_t bytes = 0;
     // cell streams of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc), one per range length in use (lds_stream_of: 4 windows per
     // wavefront x 4 / 2 / 1 / 3 planes, 8 windows x 2 / 1 planes); nranges == 0: not built
-    struct CellStream {
-        int32_t nranges = 0, nwg = 0;
+    struct CellStream {   // published by build_lds_cells under its mutex; nranges is written last (release) and read first (acquire)
+        std::atomic<int32_t> nranges{0};
+        int32_t nwg = 0;
         int64_t tiles = 0;
         uint32_t* d_cell_ptr = nullptr;    // [nwg * nranges * 16 * maxw + 1] tile offset of cell (workgroup, range, wavefront, window slot)
         uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
     };
     CellStream lds[6];   // (kLdsStreams)
-    mutable int8_t lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
-    tcgnn_plan() { for (auto& c : lds_choice) c = -1; }
-    // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches
+    mutable std::atomic<int8_t> lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
+    tcgnn_plan() { for (auto& c : lds_choice) c.store(-1, std::memory_order_relaxed); }
+    // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches; slots are claimed atomically
+    // (two streams may call into one plan)
     mutable std::vector<hipEvent_t> ev;
-    mutable int ev_used = 0;
+    mutable std::atomic<int> ev_used{0};
 };
 
 // Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
@@ -96,7 +99,11 @@ struct tcgnn_plan {
 struct KernelTimer {
     const tcgnn_plan* p; hipStream_t s; int slot = -1;
     KernelTimer(const tcgnn_plan* plan, hipStream_t stream) : p(plan), s(stream) {
-        if (p && !p->ev.empty() && 2 * p->ev_used + 1 < (int)p->ev.size()) { slot = p->ev_used++; (void)hipEventRecord(p->ev[2 * slot], s); }
+        if (p && !p->ev.empty()) {
+            const int k = p->ev_used.fetch_add(1, std::memory_order_relaxed);
+            if (2 * k + 1 < (int)p->ev.size()) { slot = k; (void)hipEventRecord(p->ev[2 * slot], s); }
+            else p->ev_used.store((int)p->ev.size() / 2, std::memory_order_relaxed);   // full: stay saturated, never wrap
+        }
     }
     ~KernelTimer() { if (slot >= 0) (void)hipEventRecord(p->ev[2 * slot + 1], s); }
 };
@@ -297,7 +304,8 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
                                                       int32_t D, int32_t Dpad, int32_t pitch,
                                                       _Float16* __restrict__ X16,
-                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr) {
+                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr, int64_t ldx = 0) {
+    if (ldx == 0) ldx = D;   // row stride of X (and G) in floats: > D when X is a column block of a wider matrix
     const int cpr = Dpad >> 3;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = ((int64_t)N + 1) * cpr;
@@ -307,19 +315,19 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
     const float s = pow2f(scale_exp_from_bits(hdr[0]));
     half8 o;
     if (row < N && VEC && d0 + 8 <= D) {
-        const float4* src = reinterpret_cast<const float4*>(X + row * D + d0);
+        const float4* src = reinterpret_cast<const float4*>(X + row * ldx + d0);
         const float4 a = src[0], b = src[1];
         o[0] = to_half_rna(a.x * s); o[1] = to_half_rna(a.y * s); o[2] = to_half_rna(a.z * s); o[3] = to_half_rna(a.w * s);
         o[4] = to_half_rna(b.x * s); o[5] = to_half_rna(b.y * s); o[6] = to_half_rna(b.z * s); o[7] = to_half_rna(b.w * s);
         if (G) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (!(G[row * D + d0 + j] > 0.0f)) o[j] = (_Float16)0.0f;
+            for (int j = 0; j < 8; ++j) if (!(G[row * ldx + d0 + j] > 0.0f)) o[j] = (_Float16)0.0f;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = d0 + j;
-            o[j] = (row < N && d < D && (!G || G[row * D + d] > 0.0f)) ? to_half_rna(X[row * D + d] * s) : (_Float16)0.0f;
+            o[j] = (row < N && d < D && (!G || G[row * ldx + d] > 0.0f)) ? to_half_rna(X[row * ldx + d] * s) : (_Float16)0.0f;
         }
     }
     *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
@@ -342,6 +350,7 @@ struct SpmmArgs {
     int64_t E;
     int32_t xrows;   // rows of X16 including the zero sentinel row
     int32_t relu;    // fused epilogue: Y = max(A X, 0) (binary SpMM only)
+    int32_t ldy;     // row stride of Y in floats (== D unless this call is one column block of a wider matrix)
 };
 
 // ---- memory pipeline discipline -----------------------------------------------------------------
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, v[ii] * inv1 * inv2);
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, v[ii] * inv1 * inv2);
             }
         }
     } else {
@@ -661,7 +670,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[s][ii] * inv1 * inv2);
+                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, acc[s][ii] * inv1 * inv2);
             }
         }
     }
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
                 if (colg < a.D) {
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
-                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[j][s][ii] * inv1 * inv2);
+                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, acc[j][s][ii] * inv1 * inv2);
                 }
             }
         }
@@ -1613,10 +1622,15 @@ static constexpr size_t kHdrBytes = 256;
 // slower than D = 64), so rows up to 128 B are padded to a power of two and longer ones to whole lines.
 static int x16_pitch(int dpad) {
     const int bytes = dpad * 2;
+    if (bytes > 128) return ((bytes + 127) / 128 * 128) / 2;   // whole lines (D = 602: 1280 B, not the 2048 B of the next power of two)
     int p = 32;
-    while (p < bytes) p <<= 1;   // power of two: 32 B .. 128 B inside one line, longer rows whole lines
+    while (p < bytes) p <<= 1;   // power of two: 32 B .. 128 B inside one line
     return p / 2;
 }
+// The gather walks address X16 through a structured buffer descriptor whose record stride (the row pitch in bytes) is a
+// 14-bit field: a wider row would wrap it (stride 0 + the swizzle bit set) and every gather would silently read the wrong row.
+static constexpr int kMaxStructStride = 16383;
+static bool pitch_fits_descriptor(int D) { return x16_pitch(round_up(D, 16)) * 2 <= kMaxStructStride; }
 
 static size_t workspace_bytes_for(int32_t N, int32_t D) {
     const size_t dpad = (size_t)x16_pitch(round_up(D, 16));
@@ -1642,9 +1656,13 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
     return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
 }
 
+// ldx > 0: X (and the gate) is a column block of a wider row-major matrix with that row stride; the scale words in the
+// header were then computed over the WHOLE matrix by the caller (block_of_wider = true: no memset, no absmax pass here), so
+// every block is rounded exactly as the undivided call would round it.
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
-                          const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr) {
+                          const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr,
+                          int64_t ldx = 0, bool block_of_wider = false) {
     const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
@@ -1652,20 +1670,20 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
     const int dpad = round_up(D, 16);
     const int pitch = x16_pitch(dpad);
-    HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
-    const int64_t nx = (int64_t)plan->Nc * D;
+    if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
+    const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
         if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr);
         else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
     }
-    if (d_val && plan->E > 0) {
+    if (d_val && plan->E > 0 && !block_of_wider) {
         const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
         hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1);
     }
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
-    const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
         if (vec && D % 16 == 0 && (!d_gate || (reinterpret_cast<uintptr_t>(d_gate) & 15) == 0)) {
             const int64_t threads = ((int64_t)plan->Nc + 1) * (D / 4);
@@ -1675,8 +1693,8 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
             hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
                                d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
         else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
-    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate);
+    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx);
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
     return TCGNN_OK;
@@ -1815,12 +1833,18 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     return TCGNN_OK;
 }
 
+// columns one gather-walk launch may cover: the widest row whose pitch the structured descriptor can express, in whole
+// 128-column chunks.  Wider matrices go through the gather walks as independent column blocks (ld = the full row length).
+static constexpr int kMaxGatherBlockDims = 4096;
+
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
-                    void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr) {
+                    void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr,
+                    int64_t ld = 0, bool block_of_wider = false) {
     if (!plan || D < 1 || (plan->N > 0 && ((!d_X && !d_staged) || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->N == 0) return TCGNN_OK;
-    if ((int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
+    if (ld == 0) ld = D;
+    if (!block_of_wider && (int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
         HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
     if (d_val && (!plan->canonical || plan->E < 4)) {
         hipLaunchKernelGGL(spmm_val_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream,
@@ -1838,7 +1862,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
-    bool lds = !d_val && !d_staged && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
+    bool lds = !d_val && !d_staged && !block_of_wider && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
                (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
     LdsPass passes[2]; int npass = 0;
     if (lds) {
@@ -1866,13 +1890,39 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             }
         }
     }
+    if (!lds && !pitch_fits_descriptor(D)) {
+        // a row too long for the gather walks' buffer descriptor: independent column blocks, every one rounded
+        // with the scale of the whole matrix (absmax over all of X / the edge values here, once)
+        if (d_staged) return fail(TCGNN_ERR_UNSUPPORTED, "tcgnn_spmm_staged: rows of %d columns exceed the %d-byte descriptor stride", D, kMaxStructStride);
+        if (block_of_wider) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: nested column blocks");
+        const size_t need = workspace_bytes_for(plan->Nc, D);
+        if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
+            return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
+        uint32_t* whdr = static_cast<uint32_t*>(ws);
+        HIP_TRY(hipMemsetAsync(whdr, 0, 16, stream));
+        const int64_t nx = (int64_t)plan->Nc * D;
+        const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr);
+        if (d_val && plan->E > 0) {
+            const int g2 = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
+            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1);
+        }
+        HIP_TRY(hipGetLastError());
+        for (int c0 = 0; c0 < D; c0 += kMaxGatherBlockDims) {
+            const int db = std::min(kMaxGatherBlockDims, D - c0);
+            const int rc = run_spmm(plan, d_X + c0, d_val, d_Y + c0, db, ws, ws_bytes, stream_v, relu, d_gate ? d_gate + c0 : nullptr, nullptr, D, true);
+            if (rc) return rc;
+        }
+        return TCGNN_OK;
+    }
     if (d_staged) {   // the caller built the (row-major) fp16 image itself: tcgnn_spmm_staged
         hdr = static_cast<const uint32_t*>(d_staged);
         x16 = reinterpret_cast<const _Float16*>(static_cast<const char*>(d_staged) + kHdrBytes);
         dpad = round_up(D, 16);
         pitch = x16_pitch(dpad);
     } else {
-        const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate);
+        const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate, block_of_wider ? ld : 0, block_of_wider);
         if (rc) return rc;
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
@@ -1886,7 +1936,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         return TCGNN_OK;
     }
-    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu};
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -2161,7 +2211,8 @@ int tcgnn_plan_set_timing(tcgnn_plan* plan, int32_t max_calls) {
 int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, int32_t* count) {
     if (!plan || !count || (capacity > 0 && !ms_out)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_read_timing: null argument");
     int n = 0;
-    for (int i = 0; i < plan->ev_used && n < capacity; ++i) {
+    const int used = std::min(plan->ev_used.load(), (int)plan->ev.size() / 2);
+    for (int i = 0; i < used && n < capacity; ++i) {
         HIP_TRY(hipEventSynchronize(plan->ev[2 * i + 1]));
         HIP_TRY(hipEventElapsedTime(&ms_out[n], plan->ev[2 * i], plan->ev[2 * i + 1]));
         ++n;

@@ -99,14 +99,27 @@ extern "C" int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_
         return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_preprocess_gpu: null array or bad size");
     if (num_edges > 0x7fffffffLL) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_preprocess_gpu: int32 CSR positions only (E = %lld)", (long long)num_edges);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const int64_t E = num_edges;
     const int32_t nwin = (int32_t)(((int64_t)num_nodes + blockSize_h - 1) / blockSize_h);
     const int64_t visited = (int64_t)num_nodes / blockSize_h + 1; // TCGNN.cpp:200 loop bound
 
-    DevBuf seg, keys, pos, flags, scan, counts, total, tmp;
+    DevBuf seg, keys, pos, flags, scan, counts, total, tmp, maxid;
     HIP_TRY(seg.alloc(((size_t)nwin + 1) * 4));
     HIP_TRY(counts.alloc((size_t)visited * 4));
     HIP_TRY(total.alloc(8));
+    HIP_TRY(maxid.alloc(4));
+    hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned)(nwin / 256 + 1)), dim3(256), 0, stream, d_nodePointer, num_nodes, blockSize_h, nwin, seg.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    // The CSR the row pointers describe, not the caller's array length, is what gets translated (the host path does the
+    // same, TCGNN.cpp:196-197): an edgeList longer than nodePointer[num_nodes] (main_tcgnn.py:45-46 sizes the edge arrays
+    // by the RAW edge count) leaves the sort outputs beyond it unwritten, and every later kernel would index with them.
+    int32_t ends[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&ends[0], seg.as<int32_t>(), 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&ends[1], seg.as<int32_t>() + nwin, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (ends[0] != 0) return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_preprocess_gpu: nodePointer[0] = %d, expected 0", ends[0]);
+    if (ends[1] < 0 || (int64_t)ends[1] > num_edges)
+        return fail(TCGNN_ERR_BAD_GRAPH, "tcgnn_preprocess_gpu: nodePointer[num_nodes] = %d but edgeList holds %lld entries", ends[1], (long long)num_edges);
+    const int64_t E = ends[1];
     HIP_TRY(keys.alloc((size_t)E * 4));
     HIP_TRY(pos.alloc((size_t)E * 4));
     HIP_TRY(flags.alloc((size_t)E * 4));
@@ -114,13 +127,23 @@ extern "C" int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_
 
     if (num_nodes > 0 && E > 0)
         hipLaunchKernelGGL(fill_edge_to_row_kernel, dim3((unsigned)((num_nodes + 3) / 4)), dim3(256), 0, stream, d_nodePointer, num_nodes, d_edgeToRow);
-    hipLaunchKernelGGL(window_offsets_kernel, dim3((unsigned)(nwin / 256 + 1)), dim3(256), 0, stream, d_nodePointer, num_nodes, blockSize_h, nwin, seg.as<int32_t>());
     HIP_TRY(hipGetLastError());
 
     if (E > 0) {
-        unsigned end_bit = 1;
-        while (end_bit < 32 && (1ull << end_bit) < (unsigned long long)num_nodes) ++end_bit;
         const uint32_t* kin = reinterpret_cast<const uint32_t*>(d_edgeList);
+        // sort as many key bits as the largest id has (ids >= num_nodes are legal here, as in the host path)
+        uint32_t host_max = 0;
+        {
+            size_t tb = 0;
+            DevBuf rtmp;
+            HIP_TRY(rocprim::reduce(nullptr, tb, kin, maxid.as<uint32_t>(), 0u, (size_t)E, rocprim::maximum<uint32_t>(), stream));
+            HIP_TRY(rtmp.alloc(tb));
+            HIP_TRY(rocprim::reduce(rtmp.p, tb, kin, maxid.as<uint32_t>(), 0u, (size_t)E, rocprim::maximum<uint32_t>(), stream));
+            HIP_TRY(hipMemcpyAsync(&host_max, maxid.p, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        unsigned end_bit = 1;
+        while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)host_max) ++end_bit;
         rocprim::counting_iterator<int32_t> vin(0);
         size_t tb_sort = 0, tb_scan = 0;
         HIP_TRY(rocprim::segmented_radix_sort_pairs(nullptr, tb_sort, kin, keys.as<uint32_t>(), vin, pos.as<int32_t>(), (unsigned)E, (unsigned)nwin,

@@ -90,31 +90,24 @@ SHAPES = {  # name: (N, nnz target, in_dim, classes) - SURVEY.md 8(d)
 }
 
 
-def synthetic_csr(num_nodes, nnz_target, seed=0, device="cpu", skew=0.0):
-    """Seeded symmetric graph without self loops, canonical CSR, nnz within ~0.1 % of the target.
-    skew = 0: uniform endpoints; skew > 0: one endpoint drawn as floor(N * u^(1+skew)) of a random
-    permutation (heavier tail).  Returns int32 (row_pointers, column_index) on `device`."""
-    dev = torch.device(device)
-    g = torch.Generator(device=dev).manual_seed(seed)
-    n = int(num_nodes)
+def _symmetric_csr(n, nnz_target, draw, g, dev, rounds=6):
+    """Canonical symmetric CSR without self loops from an endpoint sampler: draw(m) -> (a, b) int64 tensors of m candidate
+    pairs.  Pairs are symmetrised, de-duplicated and topped up until nnz is within ~0.1 % of the target (or the sampler
+    stops producing new pairs: heavy-tailed samplers saturate their hubs)."""
     half = int(nnz_target) // 2
     keys = torch.empty(0, dtype=torch.int64, device=dev)
-    want = half
-    for _ in range(6):  # top up what symmetrisation / dedup / self-loop removal ate
-        m = int(want * 1.002) + 16
-        u = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
-        if skew > 0:
-            u = u ** (1.0 + skew)
-        a = (u * n).long().clamp_(max=n - 1)
-        b = torch.randint(0, n, (m,), generator=g, device=dev)
-        if skew > 0:
-            perm = torch.randperm(n, generator=g, device=dev)
-            a = perm[a]
+    want, boost = half, 1.002
+    for _ in range(rounds):
+        m = int(want * boost) + 16
+        a, b = draw(m)
         lo, hi = torch.minimum(a, b), torch.maximum(a, b)
         keep = lo != hi
+        before = keys.numel()
         keys = torch.unique(torch.cat([keys, lo[keep] * n + hi[keep]]))
         if keys.numel() >= half:
             break
+        gained = keys.numel() - before
+        boost = min(64.0, max(boost, 1.05 * m / max(gained, 1)))   # duplicates ate (1 - gained / m) of the draw: oversample accordingly
         want = half - keys.numel()
     if keys.numel() > half:
         keys = keys[torch.randperm(keys.numel(), generator=g, device=dev)[:half]]
@@ -127,14 +120,94 @@ def synthetic_csr(num_nodes, nnz_target, seed=0, device="cpu", skew=0.0):
     return rowptr.to(torch.int32), cols.contiguous()
 
 
-def synthetic_shape(name, seed=0, device="cpu", scale=1.0):
+def synthetic_csr(num_nodes, nnz_target, seed=0, device="cpu", skew=0.0):
+    """Seeded symmetric graph without self loops, canonical CSR, nnz within ~0.1 % of the target.
+    skew = 0: uniform endpoints; skew > 0: one endpoint drawn as floor(N * u^(1+skew)) of a random
+    permutation (heavier tail).  Returns int32 (row_pointers, column_index) on `device`."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    n = int(num_nodes)
+
+    def draw(m):
+        u = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+        if skew > 0:
+            u = u ** (1.0 + skew)
+        a = (u * n).long().clamp_(max=n - 1)
+        b = torch.randint(0, n, (m,), generator=g, device=dev)
+        if skew > 0:
+            perm = torch.randperm(n, generator=g, device=dev)
+            a = perm[a]
+        return a, b
+    return _symmetric_csr(n, nnz_target, draw, g, dev)
+
+
+def rmat_csr(num_nodes, nnz_target, seed=0, device="cpu", abcd=(0.57, 0.19, 0.19, 0.05), shuffle=False):
+    """Seeded R-MAT graph (a, b, c, d = 0.57, 0.19, 0.19, 0.05), symmetrised, self loops removed, de-duplicated,
+    canonical CSR.  Endpoints are drawn in the 2^s x 2^s square (s = ceil(log2 N)) one bit per level and pairs with an
+    endpoint >= N are discarded, which keeps the recursive-quadrant distribution for any N.  Low ids are the hubs and
+    neighbouring ids share neighbourhoods: this is the locality the condensing step and the caches see; shuffle=True
+    relabels the nodes with a random permutation (a dataset whose ids carry no structure)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    n = int(num_nodes)
+    s = max(1, (n - 1).bit_length())
+    a_, b_, c_, _ = abcd
+    perm = torch.randperm(n, generator=g, device=dev) if shuffle else None
+
+    def draw(m):
+        m2 = int(m * 1.3) + 16                               # head room for the pairs that fall outside [0, N)
+        src = torch.zeros(m2, dtype=torch.int64, device=dev)
+        dst = torch.zeros(m2, dtype=torch.int64, device=dev)
+        for _ in range(s):
+            u = torch.rand(m2, generator=g, device=dev)
+            right = ((u >= a_) & (u < a_ + b_)) | (u >= a_ + b_ + c_)     # quadrants b and d: destination bit set
+            down = u >= a_ + b_                                           # quadrants c and d: source bit set
+            src = (src << 1) | down.long()
+            dst = (dst << 1) | right.long()
+        ok = (src < n) & (dst < n)
+        src, dst = src[ok], dst[ok]
+        if perm is not None:
+            src, dst = perm[src], perm[dst]
+        return src, dst
+    return _symmetric_csr(n, nnz_target, draw, g, dev, rounds=14)
+
+
+def sbm_csr(num_nodes, nnz_target, seed=0, device="cpu", blocks=50, p_in=0.9, shuffle=False):
+    """Seeded stochastic-block-model graph - the "community" variant SURVEY.md 8d asks for next to the uniform one because
+    condensing depends on locality: `blocks` equal communities of consecutive ids; an edge stays inside its first endpoint's
+    community with probability p_in, else its second endpoint is uniform.  Same post-processing as synthetic_csr.
+    shuffle=True relabels the nodes at random (communities present, but invisible to a window of 16 consecutive ids)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    n = int(num_nodes)
+    size = (n + blocks - 1) // blocks
+    perm = torch.randperm(n, generator=g, device=dev) if shuffle else None
+
+    def draw(m):
+        a = torch.randint(0, n, (m,), generator=g, device=dev)
+        inside = torch.rand(m, generator=g, device=dev) < p_in
+        blk0 = (a // size) * size
+        width = torch.clamp(blk0 + size, max=n) - blk0
+        b_in = blk0 + (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * width).long().clamp_(max=size - 1)
+        b_in = torch.minimum(b_in, blk0 + width - 1)
+        b = torch.where(inside, b_in, torch.randint(0, n, (m,), generator=g, device=dev))
+        if perm is not None:
+            a, b = perm[a], perm[b]
+        return a, b
+    return _symmetric_csr(n, nnz_target, draw, g, dev, rounds=10)
+
+
+GENERATORS = {"uniform": synthetic_csr, "rmat": rmat_csr, "sbm": sbm_csr}
+
+
+def synthetic_shape(name, seed=0, device="cpu", scale=1.0, generator="uniform"):
     """(row_pointers, column_index, in_dim, classes) for a named shape; `scale` shrinks N and nnz
-    together (tests use small scales)."""
+    together (tests use small scales); generator: "uniform", "rmat" or "sbm" (GENERATORS)."""
     n, nnz, dim, classes = SHAPES[name]
     n2 = max(16, int(n * scale))
     nnz2 = max(2, int(nnz * scale * scale)) if scale < 1.0 else nnz
     nnz2 = min(nnz2, n2 * (n2 - 1) // 2)
-    rp, col = synthetic_csr(n2, nnz2, seed=seed, device=device)
+    rp, col = GENERATORS[generator](n2, nnz2, seed=seed, device=device)
     return rp, col, dim, classes
 
 

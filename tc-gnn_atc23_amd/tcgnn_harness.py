@@ -144,7 +144,11 @@ def run(args, quiet=False):
     import TCGNN
     import tcgnn_layers as L
     say = (lambda *a, **k: None) if quiet else print
+    if args.synthetic and args.dataset == build_parser().get_default("dataset"):
+        args.dataset = args.synthetic   # the scrapers take the graph's name from `dataset=` in this line (1_log2csv.py:13-16)
     say(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("tcgnn_harness needs the GPU: the TCGNN operators have no CPU path")
     device = torch.device("cuda:0")
     ds = load_graph(args)
     num_nodes, num_edges = ds.num_nodes, ds.num_edges
@@ -169,7 +173,8 @@ def run(args, quiet=False):
 
     meta = tuple(t.to(device) for t in (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow))
     x, y = ds.x.to(device), ds.y.to(device)
-    result = {"prep_ms": prep_ms, "num_nodes": num_nodes, "nnz": int(column_index.numel())}
+    result = {"prep_ms": prep_ms, "num_nodes": num_nodes, "nnz": int(column_index.numel()), "num_edges_raw": int(num_edges),
+              "edge_arrays_len": int(edgeToColumn.numel()), "num_row_windows": int(blockPartition.numel())}
 
     if args.single_kernel:
         result["sag_ms"] = L.SAG(*meta).profile(x)

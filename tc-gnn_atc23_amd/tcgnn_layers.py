@@ -217,15 +217,25 @@ class TCGNNFunction(torch.autograd.Function):
             Y = backend().forward_fused(tall_mm(X, weights), *ctx.meta, relu=True)[0]
             ctx.save_for_backward(X, weights, Y)
             return Y
-        ctx.save_for_backward(X, weights)
         Y = backend().forward(tall_mm(X, weights), *ctx.meta)[0]
-        return torch.relu(Y) if fuse_relu else Y   # (a backend without the fused entry point: plain composition, autograd off here)
+        # a backend without the fused entry point: the same ReLU as a plain step - and, autograd being off inside a Function,
+        # its backward mask applied by hand below (ctx.masked), or dX / dW would silently miss it
+        ctx.masked = bool(fuse_relu)
+        if ctx.masked:
+            Y = torch.relu(Y)
+            ctx.save_for_backward(X, weights, Y)
+        else:
+            ctx.save_for_backward(X, weights)
+        return Y
 
     @staticmethod
     def backward(ctx, d_output):
         if ctx.fused:
             X, weights, Y = ctx.saved_tensors
             g = backend().forward_fused(d_output.contiguous(), *ctx.meta, gate=Y)[0]
+        elif getattr(ctx, "masked", False):
+            X, weights, Y = ctx.saved_tensors
+            g = backend().forward((d_output * (Y > 0)).contiguous(), *ctx.meta)[0]
         else:
             X, weights = ctx.saved_tensors
             g = backend().forward(d_output.contiguous(), *ctx.meta)[0]

@@ -76,6 +76,22 @@ def local_csr(row_pointers, column_index, layout, rank):
     return lrp, cols
 
 
+def _host_staged(group, t):
+    """gloo moves device tensors only for broadcast / all_reduce: with that backend (two test ranks sharing one GPU - RCCL
+    refuses a duplicate device - or a debugging run) the gathers below go through host memory.  Never taken under RCCL."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_rows(recv, send, group=None):
+    """recv[world * n] <- every rank's send[n] (flat, contiguous views): all_gather_into_tensor, host-staged under gloo."""
+    if _host_staged(group, send):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
 class HipShardOps:
     """The three kernels on this rank's row shard through the C ABI (GPU)."""
 
@@ -148,7 +164,7 @@ class HipShardOps:
                 dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)   # bit patterns of non-negative floats order like ints
             c.check(c.lib.tcgnn_stage_rows(x_local.data_ptr(), rows, D, word.data_ptr(), send.data_ptr(), st), "tcgnn_stage_rows")
             if world > 1:
-                dist.all_gather_into_tensor(body[: world * H].view(-1), send[:H].view(-1), group=group)
+                all_gather_rows(body[: world * H].view(-1), send[:H].view(-1), group)
             else:
                 body[:H].copy_(send[:H])
             Y = torch.empty(self.rows, D, device=dev)
@@ -243,7 +259,7 @@ class RowShard:
         send[: self.rows].copy_(x_local)
         if self.world == 1:
             return send
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        all_gather_rows(recv, send, self.group)
         return recv
 
     def place_replicated(self, x_global):

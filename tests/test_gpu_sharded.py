@@ -1,0 +1,201 @@
+"""The REAL multi-GPU path (HipShardOps: HIP kernels + both exchanges) with world_size 2 on the one GPU of the test box, and
+the 64-bit addressing of a papers100M-sized shard (BASELINE.json configs[4]).  Needs an MI355X: `pytest -m gpu`.
+
+RCCL refuses two ranks on one device, so the two processes rendezvous over gloo (127.0.0.1) and the gathers are host-staged
+(tcgnn_shard.all_gather_rows); everything else - local SGT, tcgnn_plan_create_sharded with num_cols > num_rows and a
+row offset, the three kernels on the shard, the fp16-on-the-wire exchange (one-word all-reduce of the absmax bit pattern +
+all-gather of the image slices into a strided view), autograd through the exchange and one whole sharded GCN step - is the
+code an 8-GPU run executes.  Each rank checks its results against the UNSHARDED HIP kernels on the whole graph and the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import graphs
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TIGHT = 4e-6
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tc-gnn_atc23_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import TCGNN
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, notes = {}, []
+    try:
+        for gname, (rp, col) in (("powerlaw_n6000", graphs.powerlaw_graph(6000, 60, seed=5)), ("uniform_n20000", graphs.uniform_graph(20000, 48, seed=6))):
+            n = len(rp) - 1
+            bp, e2c, e2r, _ = graphs.host_sgt(rp, col)
+            meta = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rp, col, bp, e2c, e2r)]
+            shard = S.RowShard(rp, col, device=dev)                      # HipShardOps: the product path
+            assert isinstance(shard.ops, S.HipShardOps) and shard.world == 2
+            b0, b1 = shard.layout.bounds[rank], shard.layout.bounds[rank + 1]
+            e0, e1 = int(rp[b0]), int(rp[b1])
+            for D in (64, 41):
+                rng = np.random.default_rng(100 + D)
+                X = (rng.standard_normal((n, D)) * 3.0).astype(np.float32)
+                att = rng.standard_normal(len(col)).astype(np.float32)
+                tX = torch.from_numpy(X).to(dev)
+                x_local = tX[b0:b1].contiguous()
+                Yfull = TCGNN.forward(tX, *meta)[0]
+                Y64, absY = O.spmm_f64(X, rp, col)
+                scale = torch.from_numpy(absY[b0:b1]).to(dev) + 1.0
+                tag = "%s D=%d " % (gname, D)
+                Yl = shard.spmm(x_local)                                 # fp32 all-gather + local SpMM
+                ok[tag + "spmm vs unsharded HIP"] = bool(((Yl - Yfull[b0:b1]).abs() / scale).max().item() <= TIGHT)
+                ok[tag + "spmm vs fp64"] = bool(((Yl.double().cpu() - torch.from_numpy(Y64[b0:b1])).abs() / scale.cpu()).max().item() <= 2.0 ** -9)
+                try:                                                     # fp16 on the wire: bit-identical on the same walk
+                    for mode in (1, 2):
+                        c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+                        a = shard.spmm(x_local)
+                        b = shard.spmm(x_local, wire="fp16")
+                        ok[tag + "fp16 wire == fp32 wire (mode %d)" % mode] = bool(torch.equal(a, b))
+                finally:
+                    c.lib.tcgnn_set_spmm_mode(0)
+                Yv = shard.spmm_val(x_local, torch.from_numpy(att[e0:e1]).to(dev))
+                Yvfull = TCGNN.forward_AGNN(tX, meta[0], meta[1], torch.from_numpy(att).to(dev).view(1, -1), *meta[2:])[0]
+                _, absYv = O.spmm_f64(X, rp, col, att)
+                ok[tag + "spmm_val"] = bool(((Yv - Yvfull[b0:b1]).abs() / (torch.from_numpy(absYv[b0:b1]).to(dev) + 1.0)).max().item() <= TIGHT)
+                ef = shard.sddmm(x_local)
+                effull = TCGNN.forward_ef(tX, *meta)[0]
+                _, absef = O.sddmm_f64(X, rp, col)
+                ok[tag + "sddmm"] = bool(ef.numel() == e1 - e0 and ((ef - effull[e0:e1]).abs() / (torch.from_numpy(absef[e0:e1]).to(dev) + 1.0)).max().item() <= TIGHT)
+            # autograd through the exchange (A, not A^T: the reference's convention) against the unsharded kernels
+            D = 32
+            rng = np.random.default_rng(7)
+            X = rng.standard_normal((n, D)).astype(np.float32); G = rng.standard_normal((n, D)).astype(np.float32)
+            xl = torch.from_numpy(X[b0:b1]).to(dev).requires_grad_(True)
+            (shard.aggregate(xl) * torch.from_numpy(G[b0:b1]).to(dev)).sum().backward()
+            ref = TCGNN.forward(torch.from_numpy(G).to(dev), *meta)[0][b0:b1]
+            ok[gname + " backward through the exchange"] = bool(((xl.grad - ref).abs() / (ref.abs() + 10.0)).max().item() <= 1e-5)
+            shard.ops.close()
+
+        # one whole sharded GCN training step on the HIP kernels vs the same step on the undivided graph (dense A, autograd)
+        rp, col = graphs.powerlaw_graph(500, 12, seed=9)
+        n, in_dim, hidden, classes = 500, 20, 16, 5
+        rng = np.random.default_rng(1)
+        X = (rng.standard_normal((n, in_dim)) * 0.1).astype(np.float32)
+        y = rng.integers(0, classes, size=n)
+        shard = S.RowShard(rp, col, device=dev)
+        b0, b1 = shard.layout.bounds[rank], shard.layout.bounds[rank + 1]
+        model = S.ShardedGCN(in_dim, hidden, classes, num_layers=2, dropout=0.0, seed=3).to(dev)
+        model.weights[0].data.mul_(0.1); model.weights[1].data.mul_(0.1)
+        w0 = [w.detach().clone() for w in model.weights]
+        opt = torch.optim.SGD(model.parameters(), lr=0.5)
+        loss = S.sharded_train_step(model, shard, torch.from_numpy(X[b0:b1]).to(dev), torch.from_numpy(y[b0:b1]).to(dev), opt, n)
+        A = np.zeros((n, n), np.float32)
+        for r in range(n):
+            A[r, col[rp[r]:rp[r + 1]]] = 1.0
+        At = torch.from_numpy(A).to(dev)
+        W = [w.clone().requires_grad_(True) for w in w0]
+        h = torch.relu(At @ (torch.from_numpy(X).to(dev) @ W[0]))
+        logp = torch.log_softmax(At @ (h @ W[1]), dim=1)
+        ref_loss = -logp.gather(1, torch.from_numpy(y).to(dev).view(-1, 1)).mean()
+        ref_loss.backward()
+        ok["gcn step loss"] = abs(float(loss) - float(ref_loss)) < 2e-3 * max(1.0, abs(float(ref_loss)))   # 10-bit operands in the kernels
+        for k in range(2):
+            ok["gcn step w%d" % k] = bool(torch.allclose(model.weights[k].detach(), w0[k] - 0.5 * W[k].grad, rtol=2e-2, atol=2e-4))
+        notes.append("loss %.6f ref %.6f" % (float(loss), float(ref_loss)))
+        shard.ops.close()
+    except Exception as exc:   # report, do not hang the other rank in a collective
+        import traceback
+        ok["exception"] = False
+        notes.append(traceback.format_exc())
+        raise
+    finally:
+        with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(repr(ok) + "\n" + "\n".join(notes))
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.array([int(v) for v in ok.values()] or [0]))
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_real_hip_shard_path(tmp_path):
+    assert torch.cuda.is_available()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        flags = np.load(os.path.join(tmp_path, "rank%d.npy" % r))
+        assert flags.size > 20 and flags.all(), open(os.path.join(tmp_path, "rank%d.txt" % r)).read()
+
+
+def test_shard_whose_feature_matrix_needs_64_bit_addresses():
+    """One rank's shard of a papers100M-sized run: A is 4096 x 34 000 000 and X is [34 000 000, 128] - num_cols * D = 4.35e9
+    elements, beyond 32-bit element AND byte offsets (the reference's `unsigned` address math overflows there,
+    TCGNN_kernel.cu:420).  Edges point below and above every 2^32 boundary; SpMM, edge-valued SpMM and SDDMM (A's rows sit at
+    row_offset inside X) are checked against float64 gathers on the device."""
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    dev = torch.device("cuda:0")
+    rows, num_cols, D, deg = 4096, 34_000_000, 128, 48
+    H = num_cols // 2                                   # world of 2 blocks of 17 M rows; this is rank 1's shard
+    layout = S.ShardLayout([0, H, 2 * H])
+    assert layout.num_cols == num_cols and num_cols * D > 2 ** 32
+    rng = np.random.default_rng(0)
+    # neighbours: around every overflow boundary of the element offset (2^32 / D rows) and the byte offset (2^32 / (4 D), / (2 D)), plus uniform
+    special = np.array([2 ** 32 // D, 2 ** 32 // (4 * D), 2 ** 32 // (2 * D), 2 ** 31 // D, num_cols - 1, 0], dtype=np.int64)
+    lrp = np.zeros(rows + 1, np.int32); cols = []
+    for r in range(rows):
+        cset = set(rng.integers(0, num_cols, size=deg - 8).tolist())
+        cset.update((special[rng.integers(0, len(special), size=8)] + rng.integers(-2, 3, size=8)).clip(0, num_cols - 1).tolist())
+        cc = np.array(sorted(cset), dtype=np.int64)
+        cols.append(cc); lrp[r + 1] = lrp[r] + len(cc)
+    lcol = np.concatenate(cols).astype(np.int32)
+    ops = S.HipShardOps(lrp, lcol, layout, 1, dev)      # rank 1: row_off = H
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(num_cols, D, device=dev, generator=g)               # 17.4 GB
+    tcol = torch.from_numpy(lcol).to(dev).long()
+    erow = torch.repeat_interleave(torch.arange(rows, device=dev), torch.from_numpy(np.diff(lrp)).to(dev).long())
+    Xn = X[tcol].double()                                               # [E, D] neighbour rows
+    Y = ops.spmm(X)
+    ref = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, Xn)
+    scale = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, Xn.abs()) + 1.0
+    assert ((Y.double() - ref).abs() / scale).max().item() <= 2.0 ** -9
+    att = torch.randn(tcol.numel(), device=dev, generator=g)
+    Yv = ops.spmm_val(X, att)
+    refv = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, Xn * att.double()[:, None])
+    scalev = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, (Xn * att.double()[:, None]).abs()) + 1.0
+    assert ((Yv.double() - refv).abs() / scalev).max().item() <= 2.0 ** -8
+    ef = ops.sddmm(X)
+    Xr = X[H + erow].double()                                           # A's row r is X's row row_off + r
+    refe = (Xr * Xn).sum(1); scalee = (Xr * Xn).abs().sum(1) + 1.0
+    assert ((ef.double() - refe).abs() / scalee).max().item() <= 2.0 ** -8
+    # the pre-staged fp16 image (what crosses the fabric with wire="fp16"): 8.7 GB, same kernel, same bits
+    try:
+        for mode in (1,):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            a = ops.spmm(X)                                             # the fp16 gather walk (auto mode took the small-graph kernel)
+            assert ((a.double() - ref).abs() / scale).max().item() <= 2.0 ** -9
+            # world of one process: spmm_fp16_exchange copies its own block only - build the image over all rows directly
+            pitch = c.lib.tcgnn_x16_pitch(D)
+            image = torch.zeros(256 + (num_cols + 1) * pitch * 2 + 256, dtype=torch.uint8, device=dev)
+            off = (-image.data_ptr()) % 256
+            image = image[off: off + 256 + (num_cols + 1) * pitch * 2]
+            word = image[:4].view(torch.int32)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            c.check(c.lib.tcgnn_stage_absmax(X.data_ptr(), num_cols * D, word.data_ptr(), st), "absmax")
+            c.check(c.lib.tcgnn_stage_rows(X.data_ptr(), num_cols, D, word.data_ptr(), image[256:].data_ptr(), st), "rows")
+            b = torch.empty(rows, D, device=dev)
+            c.check(c.lib.tcgnn_spmm_staged(ops.plan, image.data_ptr(), b.data_ptr(), D, st), "staged")
+            assert torch.equal(a, b)
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    ops.close()

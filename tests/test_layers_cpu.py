@@ -75,6 +75,22 @@ def test_module_facts_match_reference(layers):
     assert list(layers.GINConv(8, 4).weights.shape) == [8, 4]
 
 
+def test_fuse_relu_without_a_fused_backend_still_masks_the_gradient(layers):
+    """A direct TCGNNFunction.apply(..., True) caller on a backend that lacks forward_fused (the oracle backend here) gets the
+    plain ReLU AND its backward mask: same values and gradients as relu(TCGNNFunction.apply(...)) through autograd."""
+    f = np.load(os.path.join(GOLD, "layers_n200.npz"))
+    t = lambda k: torch.from_numpy(f[k])
+    meta = (t("rowptr"), t("col"), t("bp"), t("e2c"), t("e2r"))
+    dY = t("dY")
+    assert not hasattr(layers.backend(), "forward_fused")
+    x1, w1 = t("X").clone().requires_grad_(True), t("W").clone().requires_grad_(True)
+    y1 = layers.TCGNNFunction.apply(x1, w1, *meta, True); y1.backward(dY)
+    x2, w2 = t("X").clone().requires_grad_(True), t("W").clone().requires_grad_(True)
+    y2 = torch.relu(layers.TCGNNFunction.apply(x2, w2, *meta)); y2.backward(dY)
+    assert (y1 < 0).sum() == 0 and (y1 == 0).any()
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad) and torch.equal(w1.grad, w2.grad)
+
+
 def test_dataset_loader_matches_reference_fixture(tmp_path):
     import tcgnn_graph as G
     f = np.load(os.path.join(GOLD, "dataset_toy.npz"))
