@@ -351,6 +351,7 @@ struct SpmmArgs {
     int32_t xrows;   // rows of X16 including the zero sentinel row
     int32_t relu;    // fused epilogue: Y = max(A X, 0) (binary SpMM only)
     int32_t ldy;     // row stride of Y in floats (== D unless this call is one column block of a wider matrix)
+    int32_t big;     // the fp16 image is 4 GB or more: gathers use 64-bit lane addresses (a buffer descriptor's index * stride wraps at 2^32)
 };
 
 // ---- memory pipeline discipline -----------------------------------------------------------------
@@ -499,6 +500,15 @@ struct TileWalker {
         int shift;
     };
     template <int BUF> __device__ __forceinline__ void dma_gather(const uint32_t* cid) const {
+        if (a.big) {   // (wave-uniform: a kernel argument)
+            const char* const xb = reinterpret_cast<const char*>(a.x16);
+            const uint64_t pitchb = (uint64_t)a.stride * 2u;
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[k] * pitchb + doff[k]),
+                                                 (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NT; ++k)
             __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16,
@@ -808,6 +818,7 @@ struct SddmmArgs {
     const int32_t* rowptr;
     const uint32_t* bptr;       // range-blocked walk (nranges > 0)
     int32_t nbuckets, gsel, nranges, nw;
+    int32_t big;                // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
 };
 
 // LDS of one SDDMM wavefront: two operand buffers, the metadata pad, the output staging area
@@ -903,6 +914,16 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     };
 
     auto dma_b = [&](const uint32_t* cid, int bufbase) {
+        if (a.big) {
+            const char* const xb = reinterpret_cast<const char*>(a.x16);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[sub] * (uint64_t)(stride * 2) + boff[ks]),
+                                                     (LDS_AS void*)(uintptr_t)(ring + bufbase + (sub * KS + ks) * 1024), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -1094,6 +1115,7 @@ struct AgnnArgs {
     const int32_t* rowptr;
     const uint32_t* bptr;      // range-major walk (MAXW > 0): per-window tile offsets of the column buckets
     int32_t nbuckets, gsel, nranges, nw, ngroups;
+    int32_t big;               // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
 };
 
 static constexpr int agnn_wave_lds(int ks, bool bwd) {
@@ -1193,6 +1215,16 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             cnt = 0u; rstart = ~0u;
         };
         auto dma_b = [&](const uint32_t* cid) {
+            if (MAXW == 0 && a.big) {   // (the range-major variant, on request only, is at its register limit: the launcher keeps big images off it)
+                const char* const xb = reinterpret_cast<const char*>(a.x16);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[sub] * (uint64_t)(stride * 2) + boff[ks]),
+                                                         (LDS_AS void*)(uintptr_t)(ring + (sub * KS + ks) * 1024), 16, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -1630,6 +1662,9 @@ static int x16_pitch(int dpad) {
 // The gather walks address X16 through a structured buffer descriptor whose record stride (the row pitch in bytes) is a
 // 14-bit field: a wider row would wrap it (stride 0 + the swizzle bit set) and every gather would silently read the wrong row.
 static constexpr int kMaxStructStride = 16383;
+// ... and whose index * stride + offset is formed in 32 bits: an image of 4 GB or more (a papers100M-sized shard: 111 M rows of
+// 128 B) wraps.  The kernels then form 64-bit lane addresses instead (one v_mad_u64_u32 per gathered piece).
+static int32_t image_is_big(int32_t rows, int pitch_halves) { return ((uint64_t)rows + 1) * (uint64_t)pitch_halves * 2u >= (1ull << 32) ? 1 : 0; }
 static bool pitch_fits_descriptor(int D) { return x16_pitch(round_up(D, 16)) * 2 <= kMaxStructStride; }
 
 static size_t workspace_bytes_for(int32_t N, int32_t D) {
@@ -1863,7 +1898,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
     bool lds = !d_val && !d_staged && !block_of_wider && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
-               (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) < ((int64_t)1 << 31);
+               (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32);   // records * 32 B inside the descriptor's 32-bit offset
     LdsPass passes[2]; int npass = 0;
     if (lds) {
         // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
@@ -1936,7 +1971,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         return TCGNN_OK;
     }
-    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld};
+    SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
+               image_is_big(plan->Nc, pitch)};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -1995,14 +2031,15 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         return TCGNN_OK;
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
-               plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0};
+               plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
+               image_is_big(plan->Nc, pitch)};
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     // The range-major variant exists and is bit-compatible, but measured slower for the fused kernel on the Reddit shape
     // (D=64: 1.87 vs 1.80 ms forward, 2.39 vs 1.90 ms backward; D=32 forward is the one exception, 1.28 vs 1.55): the
     // fused loop is bound by issue slots and wavefront count (PMC: VALU+MFMA ~60 % of SIMD time, 3 instead of 4 waves
     // per SIMD with the extra accumulators), not by gather locality.  Only on request (mode 2).
-    const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0;
+    const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
     {
         KernelTimer timer(plan, stream);
@@ -2287,7 +2324,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream);
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
