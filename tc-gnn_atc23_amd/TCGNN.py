@@ -25,6 +25,7 @@ Differences from the reference that a caller can observe (all supersets, see DES
   * preprocess never writes past the end of blockPartition when num_nodes % blockSize_h == 0.
 """
 import collections
+import os
 import sys
 
 import torch
@@ -32,12 +33,51 @@ import torch
 import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
-           "plan_info", "kernel_timing", "clear_plan_cache", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
+           "plan_info", "kernel_timing", "clear_plan_cache", "set_plan_cache_size", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
            "forward_fused"]
 
-_PLAN_CACHE_SIZE = 8
-_plans = collections.OrderedDict()  # key -> (handle, tensors kept alive)
+_plan_cache_size = max(1, int(os.environ.get("TCGNN_PLAN_CACHE_SIZE", "8")))
+_plans = collections.OrderedDict()  # key -> (handle, tensors kept alive, device index)
+_retired = []                       # evicted plans waiting for the kernels that may still read them: (events, handle, tensors)
 _workspaces = {}                    # (device index, stream id) -> uint8 tensor
+
+
+def set_plan_cache_size(n):
+    """Plans (packed tile streams, ~3x the CSR's bytes each) kept per process; the least recently used one beyond this is
+    retired.  A mini-batch loop over k graphs wants n >= k.  Also the environment variable TCGNN_PLAN_CACHE_SIZE."""
+    global _plan_cache_size
+    _plan_cache_size = max(1, int(n))
+    _evict()
+
+
+def _reap(block=False):
+    """Destroy retired plans whose last possible reader has finished (stream-ordered: an event per stream this module has
+    launched on for that device, recorded at eviction time; nothing is synchronised unless block=True)."""
+    keep = []
+    for events, handle, tensors in _retired:
+        if block:
+            for e in events:
+                e.synchronize()
+        if all(e.query() for e in events):
+            _c.lib.tcgnn_plan_destroy(handle)
+        else:
+            keep.append((events, handle, tensors))
+    _retired[:] = keep
+
+
+def _evict():
+    while len(_plans) > _plan_cache_size:
+        _, (old, keep, dev_index) = _plans.popitem(last=False)
+        events = []
+        for (d, stream_id) in list(_workspaces):
+            if d == dev_index:   # the streams this module has launched kernels on, on the EVICTED plan's device
+                with torch.cuda.device(d):
+                    e = torch.cuda.Event()
+                    e.record(torch.cuda.ExternalStream(stream_id, device=d) if stream_id else torch.cuda.default_stream(d))
+                    events.append(e)
+        _retired.append((events, old, keep))
+    if _retired:
+        _reap()
 
 
 # ---------------------------------------------------------------- argument checks (TCGNN.cpp:54-56)
@@ -95,19 +135,19 @@ def _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
                                       edgeToColumn.data_ptr(), edgeToRow.data_ptr(), N, E, blockPartition.numel(),
                                       _stream_handle(dev), _c.ctypes.byref(handle))
     _c.check(st, "tcgnn_plan_create")
-    _plans[key] = (handle, tensors)
-    while len(_plans) > _PLAN_CACHE_SIZE:
-        _, (old, _keep) = _plans.popitem(last=False)
-        torch.cuda.synchronize()  # kernels still reading the evicted plan must finish first
-        _c.lib.tcgnn_plan_destroy(old)
+    _plans[key] = (handle, tensors, dev.index)
+    _evict()
     return handle
 
 
 def clear_plan_cache():
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    if torch.cuda.is_available():
+        for d in {v[2] for v in _plans.values()}:
+            torch.cuda.synchronize(d)
     while _plans:
-        _, (old, _keep) = _plans.popitem()
+        _, (old, _keep, _d) = _plans.popitem()
         _c.lib.tcgnn_plan_destroy(old)
+    _reap(block=True)
     _workspaces.clear()
 
 

@@ -89,7 +89,7 @@ def node_nll_loss(log_probs, y):
     return -log_probs.gather(1, y.view(-1, 1)).mean()
 
 
-def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9, hip_graph=False):
+def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9, hip_graph=False, tune=True):
     """The timed part of main_tcgnn.py (:141-181) on tensors that already live on the GPU:
     Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones.
     hip_graph: capture one whole epoch (forward, loss, backward, Adam step - the reference already asks for a capturable
@@ -109,6 +109,8 @@ def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, e
         optimizer.step()
         return loss
 
+    if tune:   # the tall dense products of this model: library / layout / slab count measured once, here, not inside autograd
+        L.tune(L.tune_layers(x.shape[0], [in_dim] + [hidden] * (num_layers - 1) + [classes]), device=x.device)
     for _ in range(warmup):
         train()
     torch.cuda.synchronize()

@@ -52,10 +52,11 @@ _SPLIT_ROWS = 1 << 15   # below this the plain products are fine
 # reliable there: on MI355X rocBLAS with the small operand K-contiguous runs Reddit's X W in 0.23 ms against hipBLASLt's
 # 0.37 but loses 0.99 : 0.93 at the ogbn-products shape; the weight gradient as a 256-slab batched product takes 0.18 ms
 # in rocBLAS at Reddit's shape and 1.35 against hipBLASLt's 0.67 at products'; K = 16 is 3-5x slower in rocBLAS
-# (tools/bench_tall_gemm_grid.py, bench_weight_grad.py, bench_gemm_products_shape.py).  So each (product, shape) is MEASURED
-# the first time it is met - every candidate once after a warm-up call, HIP events - and the winner kept for the process.
-# All candidates are fp32 products of the same operands (they differ in summation order only).  A first meeting inside a
-# graph capture (no synchronisation allowed) takes the first candidate and decides nothing.
+# (tools/bench_tall_gemm_grid.py, bench_weight_grad.py, bench_gemm_products_shape.py).  So there is a table (product, shape) ->
+# candidate, filled ONLY by an explicit tune() call (r1 VERDICT: measuring inside autograd Functions put hidden synchronisations
+# in the first epochs and made the choice differ from run to run); without it every product takes candidate 0, torch's default.
+# All candidates are fp32 products of the same operands (they differ in summation order only).  A rocBLAS candidate switches
+# torch's process-wide BLAS preference for the duration of its call and restores it (torch offers no per-call selector).
 _blas_switch = None   # (set, rocblas, default) once probed; False: this torch build has no such switch
 _tuned = {}           # (product, N, K, M, dtype) -> index of the winning candidate
 
@@ -128,20 +129,55 @@ _CANDIDATES = {
 
 
 def _tall(product, A, B):
+    """The candidate `tune()` recorded for this (product, shape), else candidate 0 (torch's default library and layout).
+    Nothing is measured here: a call inside an autograd Function never synchronises and never decides anything, so a
+    process that does not call tune() runs the same code on every run."""
     cands = _CANDIDATES[product]
     key = (product, A.shape[0], A.shape[1], B.shape[0] if product == "nt" else B.shape[1], A.dtype)
-    best = _tuned.get(key)
-    if best is None:
-        if torch.cuda.is_current_stream_capturing():
-            return cands[0](A, B)
+    return cands[_tuned.get(key, 0)](A, B)
+
+
+def tune(shapes, device=None, dtype=torch.float32, margin=0.05):
+    """Fill the candidate table for the tall products of a model - an explicit step, outside autograd and outside any graph
+    capture (the harness and bench.py call it before their dry epochs).  shapes: iterable of (product, N, K, M) with product
+    in {"mm", "nt", "tn"}; tune_layers() lists them for a layer stack.  Every candidate runs on random operands of that
+    shape (once to warm up, then twice under HIP events); a candidate replaces the default only if it is more than `margin`
+    faster, so near-ties (run-to-run noise) always resolve to the default.  Returns {key: (winner, times in ms)}."""
+    device = torch.device("cuda") if device is None else torch.device(device)
+    assert not torch.cuda.is_current_stream_capturing(), "tune() synchronises: call it before capturing a graph"
+    report = {}
+    g = torch.Generator(device=device).manual_seed(0)
+    for product, n, k, m in shapes:
+        key = (product, int(n), int(k), int(m), dtype)
+        if n < _SPLIT_ROWS or key in report:
+            continue
+        A = torch.randn(n, k, device=device, dtype=dtype, generator=g)
+        B = torch.randn((m, k) if product == "nt" else ((k, m) if product == "mm" else (n, m)), device=device, dtype=dtype, generator=g)
         times = []
-        for fn in cands:
+        for fn in _CANDIDATES[product]:
             fn(A, B)   # warm-up (library initialisation, workspace)
             t0, t1, t2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             t0.record(); fn(A, B); t1.record(); fn(A, B); t2.record(); t2.synchronize()
             times.append(min(t0.elapsed_time(t1), t1.elapsed_time(t2)))
-        best = _tuned[key] = min(range(len(cands)), key=times.__getitem__)
-    return cands[best](A, B)
+        best = min(range(len(times)), key=times.__getitem__)
+        if times[best] > (1.0 - margin) * times[0]:
+            best = 0
+        _tuned[key] = best
+        report[key] = (best, times)
+        del A, B
+    return report
+
+
+def tune_layers(num_nodes, dims, first_layer_needs_input_grad=False):
+    """The (product, N, K, M) list of a layer stack with widths dims = [in, hidden, ..., classes]: X W forward, dY W^T and
+    X^T G backward per layer (gnn_conv.py:59-68, 83-84)."""
+    shapes = []
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        shapes.append(("mm", num_nodes, a, b))
+        shapes.append(("tn", num_nodes, a, b))
+        if i > 0 or first_layer_needs_input_grad:
+            shapes.append(("nt", num_nodes, b, a))
+    return shapes
 
 
 def tall_tn_mm(A, B):

@@ -561,24 +561,32 @@ def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
 
 @pytest.mark.parametrize("shape", [(40000, 64, 41), (70001, 96, 16), (33000, 602, 64), (40000, 16, 64)])
 def test_tall_dense_updates_match_a_float64_product(dev, shape):
-    """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm / tall_tn_mm: library, layout and slab count measured per
-    shape on first use) against float64: fp32 GEMM accuracy, 1e-5 of the row-times-column norm bound; the library
-    preference they may switch for a call is restored afterwards, and a second call returns the same bits."""
+    """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm / tall_tn_mm) against float64: fp32 GEMM accuracy, 1e-5 of
+    the row-times-column norm bound - with the default candidates (no tune() call: nothing is measured inside a product, the
+    table stays empty) and with whatever an explicit tune() picks for the shape; the library preference a candidate may switch
+    for its call is restored afterwards, and a second call returns the same bits."""
     import tcgnn_layers as L
     n, k, m = shape
     g = torch.Generator(device=dev).manual_seed(n + k)
     A = torch.randn(n, k, device=dev, generator=g); W = torch.randn(k, m, device=dev, generator=g); G = torch.randn(n, m, device=dev, generator=g)
     before = torch.backends.cuda.preferred_blas_library()
+    saved = dict(L._tuned); L._tuned.clear()
+    got0 = {"A W": L.tall_mm(A, W), "G W^T": L.tall_nt_mm(G, W), "A^T G": L.tall_tn_mm(A, G)}
+    assert not L._tuned                                                      # a product call decides nothing
+    rep = L.tune([("mm", n, k, m), ("nt", n, m, k), ("tn", n, k, m)], device=dev)
+    assert len(rep) == 3 and all(0 <= w < len(L._CANDIDATES[key[0]]) and len(t) == len(L._CANDIDATES[key[0]]) for key, (w, t) in rep.items())
     got = {"A W": L.tall_mm(A, W), "G W^T": L.tall_nt_mm(G, W), "A^T G": L.tall_tn_mm(A, G)}
     assert torch.backends.cuda.preferred_blas_library() == before
     assert torch.equal(got["A W"], L.tall_mm(A, W)) and torch.equal(got["A^T G"], L.tall_tn_mm(A, G))   # the choice is kept
+    L._tuned.clear(); L._tuned.update(saved)
     want = {"A W": A.double() @ W.double(), "G W^T": G.double() @ W.double().t(), "A^T G": A.double().t() @ G.double()}
     bound = {"A W": A.double().norm(dim=1)[:, None] * W.double().norm(dim=0)[None, :],
              "G W^T": G.double().norm(dim=1)[:, None] * W.double().norm(dim=1)[None, :],
              "A^T G": A.double().norm(dim=0)[:, None] * G.double().norm(dim=0)[None, :]}
     for name in got:
-        err = ((got[name].double() - want[name]).abs() / bound[name]).max().item()
-        assert err < 1e-5, (name, shape, err)
+        for res in (got, got0):
+            err = ((res[name].double() - want[name]).abs() / bound[name]).max().item()
+            assert err < 1e-5, (name, shape, err)
 
 
 def test_first_call_of_a_width_inside_a_graph_capture_takes_a_gather_walk(dev, T):
@@ -687,6 +695,39 @@ def test_plan_cache_follows_in_place_mutation_and_streams(dev, T):
         tcol.copy_(torch.from_numpy(col2)); tbp.copy_(torch.from_numpy(bp2)); te2c.copy_(torch.from_numpy(e2c2))
         Y3 = T.forward(X, trp, tcol, tbp, te2c, te2r)[0].cpu().numpy()
         assert np.abs(Y3 - O.spmm(X.cpu().numpy(), rp2, col2, bp2, e2c2, e2r2)).max() < 1e-4
+
+
+def test_plan_cache_retires_plans_in_stream_order_without_synchronising(dev, T, monkeypatch):
+    """A loop over more graphs than the cache holds (a mini-batch of sub-graphs): eviction must not synchronise the device
+    (r1 VERDICT: every 9th graph did), the evicted plan must stay alive until the kernels queued on it have run, results stay
+    right, and the size is configurable."""
+    T.clear_plan_cache()
+    T.set_plan_cache_size(3)
+    calls = {"n": 0}
+    real_sync = torch.cuda.synchronize
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), real_sync(*a, **k))[1])
+    try:
+        gs = []
+        for k in range(7):
+            rp, col = graphs.uniform_graph(2000 + 16 * k, 30, seed=50 + k)
+            (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+            gs.append((rp, col, bp, e2c, e2r, meta, torch.randn(len(rp) - 1, 32, device=dev)))
+        outs = []
+        for rnd in range(3):                                   # 21 calls over 7 graphs through 3 slots: every call past the third evicts
+            for g in gs:
+                outs.append((g, T.forward(g[6], *g[5])[0]))
+        assert calls["n"] == 0, "eviction synchronised the device"
+        assert len(T._plans) == 3 and len(T._retired) <= 21
+    finally:
+        monkeypatch.undo()
+    torch.cuda.synchronize()
+    for (rp, col, bp, e2c, e2r, meta, X), Y in outs[-7:]:
+        ref = O.spmm(X.cpu().numpy(), rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+        assert np.abs(Y.cpu().numpy() - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    T.forward(gs[0][6], *gs[0][5])                             # a later call reaps what has finished
+    assert len(T._retired) == 0
+    T.set_plan_cache_size(8)
+    T.clear_plan_cache()
 
 
 def test_errors_raise_instead_of_exiting(dev, T):
