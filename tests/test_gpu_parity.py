@@ -724,8 +724,8 @@ def test_plan_cache_retires_plans_in_stream_order_without_synchronising(dev, T, 
     for (rp, col, bp, e2c, e2r, meta, X), Y in outs[-7:]:
         ref = O.spmm(X.cpu().numpy(), rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
         assert np.abs(Y.cpu().numpy() - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
-    T.forward(gs[0][6], *gs[0][5])                             # a later call reaps what has finished
-    assert len(T._retired) == 0
+    T.forward(gs[0][6], *gs[0][5])                             # a later call reaps what has finished (and retires one more itself)
+    assert len(T._retired) <= 1
     T.set_plan_cache_size(8)
     T.clear_plan_cache()
 
