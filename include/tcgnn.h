@@ -158,6 +158,10 @@ int tcgnn_set_spmm_mode(int32_t mode);
  * tcgnn_plan_read_timing waits for the recorded calls, returns their durations in milliseconds
  * (call order) and rearms the pairs. */
 int tcgnn_plan_set_timing(tcgnn_plan* plan, int32_t max_calls);
+/* Measurement aid: name of the main kernel the most recent hot-path call on this plan launched ("spmm_lds_kernel",
+ * "spmm_blocked_kernel", "spmm_kernel", "spmm_small_kernel", "sddmm_kernel", "agnn_kernel", ...; "" before the first call) -
+ * so a benchmark line names the kernel that ran instead of re-deriving the launcher's choice.  Static storage. */
+const char* tcgnn_plan_last_kernel(const tcgnn_plan* plan);
 int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, int32_t* count);
 
 /* Scratch bytes the three kernels need for feature width D (fp16 staging copy of X with one

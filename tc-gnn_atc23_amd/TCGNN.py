@@ -33,7 +33,7 @@ import torch
 import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
-           "plan_info", "kernel_timing", "clear_plan_cache", "set_plan_cache_size", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
+           "plan_info", "kernel_timing", "last_kernel", "clear_plan_cache", "set_plan_cache_size", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
            "forward_fused"]
 
 _plan_cache_size = max(1, int(os.environ.get("TCGNN_PLAN_CACHE_SIZE", "8")))
@@ -171,6 +171,11 @@ def kernel_timing(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow
     n = _c._i32(0)
     _c.check(_c.lib.tcgnn_plan_read_timing(plan, buf, 4096, _c.ctypes.byref(n)), "tcgnn_plan_read_timing")
     return [buf[i] for i in range(n.value)]
+
+
+def last_kernel(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """Not part of the reference API: name of the main kernel the most recent call on this graph launched."""
+    return _c.lib.tcgnn_plan_last_kernel(_plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)).decode()
 
 
 def _workspace(plan, D, device):

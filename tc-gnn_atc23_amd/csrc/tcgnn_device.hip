@@ -92,13 +92,15 @@ struct tcgnn_plan {
     // (two streams may call into one plan)
     mutable std::vector<hipEvent_t> ev;
     mutable std::atomic<int> ev_used{0};
+    mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
 };
 
 // Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
 // stream it is launched on, when timing is enabled and a pair is free.
 struct KernelTimer {
     const tcgnn_plan* p; hipStream_t s; int slot = -1;
-    KernelTimer(const tcgnn_plan* plan, hipStream_t stream) : p(plan), s(stream) {
+    KernelTimer(const tcgnn_plan* plan, hipStream_t stream, const char* kernel_name = nullptr) : p(plan), s(stream) {
+        if (p && kernel_name) p->last_kernel.store(kernel_name, std::memory_order_relaxed);
         if (p && !p->ev.empty()) {
             const int k = p->ev_used.fetch_add(1, std::memory_order_relaxed);
             if (2 * k + 1 < (int)p->ev.size()) { slot = k; (void)hipEventRecord(p->ev[2 * slot], s); }
@@ -1890,7 +1892,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
     if (!d_val && !d_staged && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
         const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu};
-        KernelTimer timer(plan, stream);
+        KernelTimer timer(plan, stream, "spmm_small_kernel");
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
@@ -1962,7 +1964,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
-        KernelTimer timer(plan, stream);
+        KernelTimer timer(plan, stream, "spmm_lds_kernel");
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
             SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
@@ -1974,10 +1976,10 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
                image_is_big(plan->Nc, pitch)};
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
-    KernelTimer timer(plan, stream);
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
+    KernelTimer timer(plan, stream, blocked ? "spmm_blocked_kernel" : "spmm_kernel");
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
         if (const char* e = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // tuning experiments only
@@ -2042,7 +2044,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
     {
-        KernelTimer timer(plan, stream);
+        KernelTimer timer(plan, stream, "agnn_kernel");
         hipError_t e;
         if (blocked) {
             size_t range_bytes = 4 * kRangeTargetBytes;
@@ -2232,6 +2234,8 @@ int tcgnn_set_spmm_mode(int32_t mode) {
     return TCGNN_OK;
 }
 
+const char* tcgnn_plan_last_kernel(const tcgnn_plan* plan) { return plan ? plan->last_kernel.load(std::memory_order_relaxed) : ""; }
+
 int tcgnn_plan_set_timing(tcgnn_plan* plan, int32_t max_calls) {
     if (!plan || max_calls < 0) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_timing: bad argument");
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
@@ -2326,7 +2330,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};
     const int ks = (dpad + 31) / 32;
-    KernelTimer timer(plan, stream);
+    KernelTimer timer(plan, stream, ks <= 4 ? "sddmm_kernel" : "sddmm_wide_kernel");
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,

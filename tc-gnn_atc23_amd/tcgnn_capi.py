@@ -48,6 +48,7 @@ SIGNATURES = {
     "tcgnn_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfo)]),
     "tcgnn_set_spmm_mode": (ctypes.c_int, [_i32]),
     "tcgnn_plan_set_timing": (ctypes.c_int, [_vp, _i32]),
+    "tcgnn_plan_last_kernel": (ctypes.c_char_p, [_vp]),
     "tcgnn_plan_read_timing": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), _i32, ctypes.POINTER(_i32)]),
     "tcgnn_workspace_bytes": (_sz, [_vp, _i32]),
     "tcgnn_spmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
@@ -73,3 +74,18 @@ def check(status, what):
         msg = lib.tcgnn_last_error().decode("utf-8", "replace")
         kind = lib.tcgnn_status_string(status).decode()
         raise RuntimeError("%s failed: %s (%s)" % (what, kind, msg))
+
+
+def build_id():
+    """Identity of the kernels this process runs: SHA-256 over the library's sources (csrc/*.hip, *.inc, *.cpp, *.h, Makefile and
+    include/tcgnn.h), 16 hex digits.  Profiles under profiles/ are keyed by it: bench.py quotes PMC numbers only when they were
+    collected from the same sources (tools/collect_profiles.py), never a stale lookup."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".inc", ".cpp", ".h")) or f == "Makefile")
+    for f in [os.path.join(src, f) for f in files] + [os.path.join(os.path.dirname(_HERE), "include", "tcgnn.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

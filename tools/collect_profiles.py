@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Collects the rocprofv3 evidence bench.py's line is judged against.  Run ON the GPU box from the repo root (through gpurun):
+
+    python tools/collect_profiles.py r02 [--quick]      -> gpurun_out/profiles_r02/   (copy what is judged into profiles/r02/)
+
+  1. `rocprofv3 --kernel-trace --stats` of the default bench command (per-kernel average durations: the number
+     roofline.kernel_ms_mean_all_launches must agree with) and of one GCN / one AGNN training run (epoch composition);
+  2. PMC passes on every kernel of the path, per workload (Reddit shape D = 64; ogbn-products shape D = 128; uniform graphs, and
+     with --all-generators the R-MAT and community variants): one counter group per run, never combined with a tracing domain
+     other than kernel-trace - FETCH_SIZE | WRITE_SIZE | TCC_HIT/MISS | GRBM_GUI_ACTIVE | SQ wave-state + MFMA counters;
+  3. traffic.json: per (kernel, workload) the HBM-side bytes per launch, (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 - the gfx950
+     correction of MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 128-byte requests at 64 B - L2 hit rate, MFMA pipe-busy fraction
+     (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)), useful MFMA fraction (2 E D / (MFMA instructions x
+     16384 flop)) and the wave-state split, keyed by tcgnn_capi.build_id(): bench.py refuses an entry from other sources."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tc-gnn_atc23_amd"))
+TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r02"
+QUICK = "--quick" in sys.argv
+ALLGEN = "--all-generators" in sys.argv
+OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + TAG)
+os.makedirs(OUT, exist_ok=True)
+ENV = dict(os.environ, TMPDIR="/tmp")
+PMC_GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["GRBM_GUI_ACTIVE"],
+              ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]]
+KERNELS = ("spmm", "sddmm", "agnn_kernel")
+
+
+def rocprof(args, cmd, outdir, log):
+    full = ["rocprofv3"] + args + ["--output-format", "csv", "-d", outdir, "-o", "p", "--"] + cmd
+    with open(log, "w") as f:
+        return subprocess.run(full, cwd="/tmp", env=ENV, stdout=f, stderr=subprocess.STDOUT, timeout=1500).returncode
+
+
+def find(outdir, pattern):
+    return glob.glob(os.path.join(outdir, "**", pattern), recursive=True)
+
+
+def stats(cmd, name):
+    d = os.path.join(OUT, "stats_" + name)
+    rc = rocprof(["--kernel-trace", "--stats"], cmd, d, os.path.join(OUT, name + ".log"))
+    f = find(d, "*kernel_stats.csv")
+    if f:
+        shutil.copy(f[0], os.path.join(OUT, name + "_kernel_stats.csv"))
+    shutil.rmtree(d, ignore_errors=True)
+    return rc
+
+
+def pmc_workload(shape, gen, D):
+    tag = "%s_%s_d%d" % (shape.replace("ogbn-", ""), gen, D)
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = ""
+    for grp in PMC_GROUPS:
+        d = os.path.join(OUT, "pmc_" + tag + "_" + grp[0])
+        log = os.path.join(OUT, "pmc_%s_%s.log" % (tag, grp[0]))
+        rocprof(["--pmc"] + grp + ["--kernel-trace"], [sys.executable, os.path.join(ROOT, "tools", "run_kernels_for_pmc.py"), shape, gen, str(D)], d, log)
+        for f in find(d, "*counter_collection*.csv"):
+            for r in csv.DictReader(open(f)):
+                k = r.get("Kernel_Name", "")
+                if any(s in k for s in KERNELS) and "csr_kernel" not in k:
+                    per_kernel[k.split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        try:
+            meta = [l for l in open(log) if l.startswith("E=")][-1].strip()
+        except (OSError, IndexError):
+            pass
+        shutil.rmtree(d, ignore_errors=True)
+    E, N = (int(meta.split()[0][2:]), int(meta.split()[1][2:])) if meta else (0, 0)
+    rows = []
+    for k, d in sorted(per_kernel.items()):
+        c = {name: sum(v) / len(v) for name, v in d.items()}
+        row = {"kernel": k, "workload": tag, "round": TAG, "edges": E, "nodes": N, "D": D, "counters_mean_per_launch": c}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            row["hbm_bytes_per_launch"] = int((c["FETCH_SIZE"] * 2 + c["WRITE_SIZE"]) * 1024)
+        if "TCC_HIT_sum" in c:
+            row["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            row["mfma_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+        if c.get("SQ_INSTS_MFMA", 0) > 0 and E:
+            useful = 2.0 * E * D * (2 if "agnn_kernel" in k else 1)      # the fused pair: scores + aggregation
+            row["mfma_useful_frac"] = round(useful / (c["SQ_INSTS_MFMA"] * 16384.0), 4)
+        if "SQ_WAVE_CYCLES" in c:
+            row["wave_issuing"] = round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+            row["wave_issue_stalled"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+            row["wave_parked"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+        rows.append(row)
+    return rows
+
+
+def main():
+    import tcgnn_capi
+    bid = tcgnn_capi.build_id()
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra", "--no-cpu", "--steps", "20", "--warmup", "5"]
+    stats(bench, "bench_spmm_reddit_d64")
+    try:   # the line printed under the profiler, next to the profiler's own average
+        line = [l for l in open(os.path.join(OUT, "bench_spmm_reddit_d64.log")) if l.startswith("{")][-1]
+        open(os.path.join(OUT, "bench_line_under_rocprof.json"), "w").write(line)
+    except (OSError, IndexError):
+        pass
+    if not QUICK:
+        harness = [sys.executable, os.path.join(ROOT, "tc-gnn_atc23_amd", "tcgnn_harness.py"), "--synthetic", "reddit", "--dim", "602", "--hidden", "64",
+                   "--classes", "41", "--epochs", "10", "--gpu_preprocess", "--model"]
+        stats(harness + ["gcn"], "epoch_gcn")
+        stats(harness + ["agnn"], "epoch_agnn")
+    rows = []
+    work = [("reddit", "uniform", 64)] if QUICK else [("reddit", "uniform", 64), ("ogbn-products", "uniform", 128)]
+    if ALLGEN:
+        work += [("reddit", "sbm", 64), ("reddit", "rmat", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]
+    for shape, gen, D in work:
+        rows += pmc_workload(shape, gen, D)
+    json.dump({"build_id": bid, "round": TAG, "how": __doc__.split("3. traffic.json:")[1].strip(), "rows": rows},
+              open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+    for r in rows:
+        print("%-34s %-24s hbm %8.1f MB  l2hit %s  mfma_busy %s useful %s  issuing/stalled/parked %s/%s/%s" % (
+            r["kernel"][:34], r["workload"], r.get("hbm_bytes_per_launch", 0) / 1e6, r.get("l2_hit_rate"), r.get("mfma_busy"), r.get("mfma_useful_frac"),
+            r.get("wave_issuing"), r.get("wave_issue_stalled"), r.get("wave_parked")))
+    for f in glob.glob(os.path.join(OUT, "**", "*"), recursive=True):   # keep what is judged, drop bulky leftovers
+        if os.path.isfile(f) and os.path.getsize(f) > 4 << 20:
+            os.remove(f)
+
+
+if __name__ == "__main__":
+    main()
