@@ -188,6 +188,17 @@ int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D,
 int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_gate, float* d_Y, int32_t D,
                      int32_t flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* f3, the dense update itself: Y[N, D_out] = (A_bin * X) * W in one launch - the GIN order of the reference
+ * (gnn_conv.py:92-97: X' = TCGNN.forward(X, ...)[0]; X' = torch.mm(X', weights)), which the harness also uses for a GCN layer that
+ * narrows (A (H W) = (A H) W).  X [N, D_in] and W [D_in, D_out] fp32 row-major, D_in, D_out <= 128.  The aggregated rows never
+ * leave the chip: each window's 16 x D_in fp32 sums go through LDS into the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 - the exact
+ * fp32 products and fp32 accumulation of the torch.mm it replaces) against W, which is read through the caches.  On the
+ * LDS-resident kernel a 64-column input is two 32-column passes whose products are added into a zeroed Y (two addends: the
+ * result does not depend on their order).  flags: TCGNN_FUSE_RELU (not when the product is accumulated over passes: the call
+ * then returns TCGNN_ERR_UNSUPPORTED, as it does for wider matrices, and the caller composes tcgnn_spmm with its own GEMM). */
+int tcgnn_spmm_gemm(const tcgnn_plan* plan, const float* d_X, const float* d_W, float* d_Y, int32_t D_in, int32_t D_out, int32_t flags,
+                    void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Pre-staged operand (no counterpart in the reference, which is single-GPU).  The kernels read a scaled fp16 image of X that
  * tcgnn_spmm builds per call inside the workspace.  A caller may build it itself - in a row-sharded run every rank converts
  * only ITS rows and the fp16 image, not fp32 X, crosses the fabric (half the bytes of the all-gather, no staging of the

@@ -34,7 +34,7 @@ import tcgnn_capi as _c
 
 __all__ = ["preprocess", "preprocess_gpu", "forward", "forward_ef", "forward_AGNN", "backward", "backward_ef",
            "plan_info", "kernel_timing", "last_kernel", "clear_plan_cache", "set_plan_cache_size", "agnn_fused_supported", "agnn_fused_forward", "agnn_fused_backward",
-           "forward_fused"]
+           "forward_fused", "forward_gemm"]
 
 _plan_cache_size = max(1, int(os.environ.get("TCGNN_PLAN_CACHE_SIZE", "8")))
 _plans = collections.OrderedDict()  # key -> (handle, tensors kept alive, device index)
@@ -302,6 +302,41 @@ def forward_fused(input, nodePointer, edgeList, blockPartition, edgeToColumn, ed
         st = _c.lib.tcgnn_spmm_fused(plan, input.data_ptr(), gate.data_ptr() if gate is not None else None, out.data_ptr(), D,
                                      1 if relu else 0, ws, ws_bytes, _stream_handle(dev))
     _c.check(st, "tcgnn_spmm_fused")
+    return [out]
+
+
+GEMM_FUSED_MAX_DIM = 128
+
+
+def forward_gemm(input, weights, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, relu=False):
+    """Not in the reference module: [(A @ input) @ weights] in ONE launch - the GIN order of
+    gnn_conv.py:92-97 (`X' = TCGNN.forward(X, ...)[0]; X' = torch.mm(X', weights)`) without the N x D_in round trip: the
+    aggregated rows go from the accumulators through LDS into the fp32 matrix pipe against W.  input [N, D_in], weights
+    [D_in, D_out], both <= 128 wide.  relu=True fuses max(., 0) where the kernel writes the product in one pass; where it
+    accumulates over column passes (the LDS-resident kernel on a 64-column input) the ReLU runs as a separate step here."""
+    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    _check_input(weights, "weights")
+    _check_float(weights, "weights")
+    N, D = input.shape
+    if weights.dim() != 2 or weights.shape[0] != D or weights.device != input.device:
+        raise RuntimeError("weights must be [input.size(1), D_out] on the input's device")
+    Dout = weights.shape[1]
+    if D > GEMM_FUSED_MAX_DIM or Dout > GEMM_FUSED_MAX_DIM or D == 0 or Dout == 0:
+        raise RuntimeError("forward_gemm covers 1 <= D_in, D_out <= %d (got %d -> %d): compose forward() with torch.mm" % (GEMM_FUSED_MAX_DIM, D, Dout))
+    dev = input.device
+    out = torch.empty(N, Dout, dtype=torch.float32, device=dev)
+    if N == 0:
+        return [out]
+    with torch.cuda.device(dev):
+        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+        ws, ws_bytes = _workspace(plan, D, dev)
+        st = _c.lib.tcgnn_spmm_gemm(plan, input.data_ptr(), weights.data_ptr(), out.data_ptr(), D, Dout, 1 if relu else 0, ws, ws_bytes,
+                                    _stream_handle(dev))
+        if st == 6 and relu:   # TCGNN_ERR_UNSUPPORTED: the product is accumulated over column passes - ReLU as its own step
+            st = _c.lib.tcgnn_spmm_gemm(plan, input.data_ptr(), weights.data_ptr(), out.data_ptr(), D, Dout, 0, ws, ws_bytes, _stream_handle(dev))
+            _c.check(st, "tcgnn_spmm_gemm")
+            return [torch.relu_(out)]
+    _c.check(st, "tcgnn_spmm_gemm")
     return [out]
 
 

@@ -354,7 +354,27 @@ struct SpmmArgs {
     int32_t relu;    // fused epilogue: Y = max(A X, 0) (binary SpMM only)
     int32_t ldy;     // row stride of Y in floats (== D unless this call is one column block of a wider matrix)
     int32_t big;     // the fp16 image is 4 GB or more: gathers use 64-bit lane addresses (a buffer descriptor's index * stride wraps at 2^32)
+    const float* w;  // f3: dense update fused behind the aggregation, Y[N, dout] = (A X) W with W [D, dout] fp32 row-major (nullptr: Y = A X)
+    int32_t dout;
 };
+
+// ---- f3: the dense update in the aggregation kernel's epilogue (gnn_conv.py:92-97: X' = TCGNN.forward(X); X' = mm(X', W)).
+// A window's aggregated rows Acc[16][din] (fp32, true scale) sit in LDS scratch `acc_lds` (row-major, leading dimension ldp, odd:
+// conflict-free column reads); one wavefront multiplies them by the W columns of output tile t on the fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact fp32 fma chain, the precision of the torch.mm it replaces) and returns C[row 4g+ii][col 16t+i].
+// W (<= 128 x 128 floats) is read through the caches: every window re-reads the same 64 KB at most.
+__device__ __forceinline__ floatx4 dense_update_tile(const float* acc_lds, int ldp, int din, const float* __restrict__ w, int k0, int dout,
+                                                     int t, int g, int i) {
+    floatx4 c = {0.f, 0.f, 0.f, 0.f};
+    const int n = 16 * t + i;
+    for (int kk = 0; kk < din; kk += 4) {
+        const int k = kk + g;
+        const float av = k < din ? acc_lds[i * ldp + k] : 0.0f;
+        const float bv = (k < din && n < dout) ? w[(int64_t)(k0 + k) * dout + n] : 0.0f;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
+    }
+    return c;
+}
 
 // ---- memory pipeline discipline -----------------------------------------------------------------
 // With an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of ANY ordinary load result and
@@ -655,6 +675,47 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
     // ---- combine the wavefronts' partial sums in a fixed order and store
     const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f; // |kx + ka| may exceed 126: two factors
     const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
+    if constexpr (!VAL) {
+        if (a.w) {   // f3: Y[window] = (A X)[window] W   (one pass: the launcher only takes this path for D <= 128)
+            const int din = NT * 16;                               // (padding columns of X16 are zero)
+            const int ldp = din + 1;
+            float* accT = reinterpret_cast<float*>(smem) + (WAVES > 1 ? WAVES * NT * 256 : 0);   // behind the reduction buffer
+            __syncthreads(); // every wave is done with its ring
+            if constexpr (WAVES > 1) {
+                floatx4* red = reinterpret_cast<floatx4*>(smem);
+#pragma unroll
+                for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
+                __syncthreads();
+                for (int s = wave; s < NT; s += WAVES) {
+                    floatx4 v = red[s * 64 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < WAVES; ++ww) {
+                        const floatx4 o = red[(ww * NT + s) * 64 + lane];
+                        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) accT[(4 * g + ii) * ldp + 16 * s + i] = v[ii] * inv1;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NT; ++s)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) accT[(4 * g + ii) * ldp + 16 * s + i] = acc[s][ii] * inv1;
+            }
+            __syncthreads();
+            const int tiles = (a.dout + 15) >> 4;
+            for (int t = wave; t < tiles; t += WAVES) {
+                const floatx4 c = dense_update_tile(accT, ldp, a.D < din ? a.D : din, a.w, 0, a.dout, t, g, i);
+                const int colg = 16 * t + i;
+                if (colg < a.dout) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, c[ii]);
+                }
+            }
+            return;
+        }
+    }
     if constexpr (WAVES > 1) {
         __syncthreads(); // every wave is done with its ring
         floatx4* red = reinterpret_cast<floatx4*>(smem);
@@ -1876,13 +1937,13 @@ static constexpr int kMaxGatherBlockDims = 4096;
 
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
                     void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr,
-                    int64_t ld = 0, bool block_of_wider = false) {
+                    int64_t ld = 0, bool block_of_wider = false, const float* d_W = nullptr, int32_t D_out = 0) {
     if (!plan || D < 1 || (plan->N > 0 && ((!d_X && !d_staged) || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->N == 0) return TCGNN_OK;
     if (ld == 0) ld = D;
     if (!block_of_wider && (int64_t)plan->nw_eff * kWinRows < plan->N) // windows the caller did not describe stay zero, like zeros_like
-        HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
+        HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * (d_W ? D_out : D) * sizeof(float), stream));
     if (d_val && (!plan->canonical || plan->E < 4)) {
         hipLaunchKernelGGL(spmm_val_csr_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream,
                            plan->rowptr, plan->col, d_val, d_X, d_Y, plan->N, D);
@@ -1890,7 +1951,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return TCGNN_OK;
     }
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
-    if (!d_val && !d_staged && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
+    if (!d_val && !d_staged && !d_W && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
         const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu};
         KernelTimer timer(plan, stream, "spmm_small_kernel");
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
@@ -1901,6 +1962,9 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
     bool lds = !d_val && !d_staged && !block_of_wider && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
                (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32);   // records * 32 B inside the descriptor's 32-bit offset
+    // f3 on the LDS-resident kernel: one pass stores its product, the two 32-column passes of a 64-column matrix ADD theirs into a
+    // zeroed Y (two addends: the sum does not depend on their order); wider inputs would need an ordered reduction - gather walk
+    if (lds && d_W && !(round_up(D, 16) <= 64 && !g_lds_maxw)) lds = false;
     LdsPass passes[2]; int npass = 0;
     if (lds) {
         // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
@@ -1964,21 +2028,29 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
     if (lds) {
+        int total_chunks = 0;
+        for (int i = 0; i < npass; ++i) total_chunks += passes[i].nchunks;
+        const int accumulate = (d_W && total_chunks > 1) ? 1 : 0;
+        if (accumulate) {
+            if (relu) return fail(TCGNN_ERR_UNSUPPORTED, "tcgnn_spmm_gemm: ReLU cannot be fused when the product is accumulated over column passes");
+            HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D_out * sizeof(float), stream));
+        }
         KernelTimer timer(plan, stream, "spmm_lds_kernel");
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
             SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
-                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu};
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu, d_W, D_out, accumulate};
             HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
         }
         return TCGNN_OK;
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
-               image_is_big(plan->Nc, pitch)};
+               image_is_big(plan->Nc, pitch), d_W, D_out};
+    if (d_W) a.ldy = D_out;
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const bool blocked = plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
+    const bool blocked = !d_W && plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
     KernelTimer timer(plan, stream, blocked ? "spmm_blocked_kernel" : "spmm_kernel");
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
@@ -2276,6 +2348,15 @@ int tcgnn_spmm_fused(const tcgnn_plan* plan, const float* d_X, const float* d_ga
                      void* ws, size_t ws_bytes, void* stream) {
     if (flags & ~TCGNN_FUSE_RELU) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_fused: unknown flag bits 0x%x", flags & ~TCGNN_FUSE_RELU);
     return run_spmm(plan, d_X, nullptr, d_Y, D, ws, ws_bytes, stream, (flags & TCGNN_FUSE_RELU) ? 1 : 0, d_gate);
+}
+
+int tcgnn_spmm_gemm(const tcgnn_plan* plan, const float* d_X, const float* d_W, float* d_Y, int32_t D_in, int32_t D_out, int32_t flags,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (flags & ~TCGNN_FUSE_RELU) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_gemm: unknown flag bits 0x%x", flags & ~TCGNN_FUSE_RELU);
+    if (!d_W || D_out < 1) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_gemm: null W or D_out < 1");
+    if (D_in > kMaxChunkDims || D_out > kMaxChunkDims)
+        return fail(TCGNN_ERR_UNSUPPORTED, "tcgnn_spmm_gemm: the fused dense update covers D_in, D_out <= %d (got %d -> %d)", kMaxChunkDims, D_in, D_out);
+    return run_spmm(plan, d_X, nullptr, d_Y, D_in, ws, ws_bytes, stream, (flags & TCGNN_FUSE_RELU) ? 1 : 0, nullptr, nullptr, 0, false, d_W, D_out);
 }
 
 int tcgnn_x16_pitch(int32_t D) { return D < 1 ? 0 : x16_pitch(round_up(D, 16)); }

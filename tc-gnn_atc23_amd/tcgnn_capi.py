@@ -54,6 +54,7 @@ SIGNATURES = {
     "tcgnn_spmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_spmm_val": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_spmm_fused": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "tcgnn_spmm_gemm": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "tcgnn_x16_pitch": (ctypes.c_int, [_i32]),
     "tcgnn_stage_absmax": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "tcgnn_stage_rows": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@ the GPU box), `--graph_dir` relocates tcgnn-ae-graphs/, `--gpu_preprocess` uses 
 `run(args)` returns the measured numbers so bench.py and the tests can call it in-process.
 """
 import argparse
+import os
 import os.path as osp
 import time
 
@@ -19,6 +20,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 BLK_H, BLK_W = 16, 8  # config.py:1-2
+# f3: a GCN layer that WIDENS (the classifier at the artifact's hidden = 16: 16 -> 22 .. 121 classes) is evaluated as (A H) W in
+# one launch (tcgnn_spmm_gemm: aggregation at the narrow width, dense update in the kernel's epilogue) instead of A (H W) - the
+# same matrix, fewer columns through the aggregation.  "auto": exactly those layers; "1" / "0": every eligible layer / none.
+AGGREGATE_FIRST = os.environ.get("TCGNN_AGGREGATE_FIRST", "auto")
 
 
 def build_parser():
@@ -62,7 +67,13 @@ class Net(nn.Module):
         x = F.dropout(x, training=self.training)
         for conv in self.hidden_layers:
             x = self._act(conv, x, meta)
-        x = self.conv2(x, *meta)
+        import tcgnn_layers as L
+        din, dout = self.conv2.weights.shape
+        want = AGGREGATE_FIRST in (True, "1") or (AGGREGATE_FIRST == "auto" and din < dout)
+        if want and isinstance(self.conv2, L.GCNConv) and max(din, dout) <= 128:
+            x = self.conv2(x, *meta, aggregate_first=True)
+        else:
+            x = self.conv2(x, *meta)
         return F.log_softmax(x, dim=1)
 
 

@@ -243,12 +243,20 @@ class TCGNNFunction(torch.autograd.Function):
     """GCN layer: dense update first, aggregation second."""
 
     @staticmethod
-    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False):
+    def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False, aggregate_first=False):
         """fuse_relu (not in the reference): the ReLU that follows the layer (main_tcgnn.py:100-139) runs in the
         SpMM kernel's stores, and its backward mask is applied to dY while dY is staged - relu(layer(x)) without the two
-        element-wise passes over N x D.  Same values as F.relu(layer(x)), bit for bit."""
+        element-wise passes over N x D.  Same values as F.relu(layer(x)), bit for bit.
+        aggregate_first (f3, opt-in): A (X W) evaluated as (A X) W in ONE launch (backend().forward_gemm: the dense update in the
+        aggregation kernel's epilogue) - the same matrix, rounded at a different point (X, not X W, meets the 10-bit operand
+        rounding).  The backward pass is unchanged: it only needs X, W and dY."""
         ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
         ctx.fused = bool(fuse_relu) and hasattr(backend(), "forward_fused")
+        if aggregate_first and not fuse_relu and hasattr(backend(), "forward_gemm") and max(weights.shape) <= 128:
+            ctx.fused = False
+            ctx.masked = False
+            ctx.save_for_backward(X, weights)
+            return backend().forward_gemm(X, weights, *ctx.meta)[0]
         if ctx.fused:
             Y = backend().forward_fused(tall_mm(X, weights), *ctx.meta, relu=True)[0]
             ctx.save_for_backward(X, weights, Y)
@@ -277,7 +285,7 @@ class TCGNNFunction(torch.autograd.Function):
             g = backend().forward(d_output.contiguous(), *ctx.meta)[0]
         # the input features of the first layer need no gradient: skip their N x in_dim product
         d_input = tall_nt_mm(g, weights) if ctx.needs_input_grad[0] else None
-        return (d_input, tall_tn_mm(X, g)) + (None,) * 6
+        return (d_input, tall_tn_mm(X, g)) + (None,) * 7
 
 
 class TCGNNFunction_GIN(torch.autograd.Function):
@@ -286,6 +294,10 @@ class TCGNNFunction_GIN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
         ctx.meta = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
+        if not any(ctx.needs_input_grad[:2]) and hasattr(backend(), "forward_gemm") and max(weights.shape) <= 128:
+            # inference: the dense update runs in the aggregation kernel's epilogue (f3), A X never reaches memory.  Training
+            # keeps the two steps: the weight gradient is (A X)^T dY (gnn_conv.py:111) and needs A X
+            return backend().forward_gemm(X, weights, *ctx.meta)[0]
         agg = backend().forward(X, *ctx.meta)[0]
         ctx.save_for_backward(agg, weights)
         return tall_mm(agg, weights)
@@ -390,7 +402,9 @@ class GCNConv(torch.nn.Module):
         bound = 1.0 / math.sqrt(self.weights.size(1))
         self.weights.data.uniform_(-bound, bound)
 
-    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False):
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, fuse_relu=False, aggregate_first=False):
+        if aggregate_first and not fuse_relu:
+            return TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, False, True)
         if fuse_relu and hasattr(backend(), "forward_fused"):
             return TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, True)
         y = TCGNNFunction.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)

@@ -796,6 +796,106 @@ def test_full_size_reddit_shape_properties(dev, T):
     assert abs(lhs - rhs) <= 1e-5 * ef.double().abs().sum().item()
 
 
+GEMM_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n1000", "empty_middle_window_n48", "powerlaw_n1000", "citeseer_shape", "dense_n3000_deg150", "no_edges_n20")]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+@pytest.mark.parametrize("dims", [(64, 41), (16, 16), (41, 7), (128, 128), (96, 33), (32, 64)])
+def test_dense_update_fused_behind_the_aggregation(dev, T, case, dims):
+    """f3: forward_gemm(X, W) = (A X) W in one launch (gnn_conv.py:92-97 as one kernel) against the two steps it replaces -
+    forward() then an fp64 product of the fp32 aggregate - at accumulation-noise distance, with and without the fused ReLU."""
+    _, rp, col = case
+    din, dout = dims
+    n = len(rp) - 1
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(din * 131 + dout + n)
+    X = rng.standard_normal((n, din)).astype(np.float32); W = (rng.standard_normal((din, dout)) / np.sqrt(din)).astype(np.float32)
+    tX, tW = to_dev(dev, X, W)
+    agg = T.forward(tX, *meta)[0]
+    want = agg.double() @ tW.double()
+    bound = agg.double().abs() @ tW.double().abs() + 1.0
+    got = T.forward_gemm(tX, tW, *meta)[0]
+    assert got.shape == (n, dout) and got.dtype == torch.float32
+    assert n == 0 or ((got.double() - want).abs() / bound).max().item() <= 4e-6
+    got_r = T.forward_gemm(tX, tW, *meta, relu=True)[0]
+    assert n == 0 or ((got_r.double() - want.clamp(min=0)).abs() / bound).max().item() <= 4e-6
+    assert torch.equal(got, T.forward_gemm(tX, tW, *meta)[0])                      # deterministic
+    with pytest.raises(RuntimeError, match="D_in, D_out <= 128"):
+        T.forward_gemm(torch.zeros(n, 129, device=dev), torch.zeros(129, 4, device=dev), *meta)
+
+
+@pytest.mark.parametrize("dims", [(64, 41), (32, 48), (41, 64), (48, 16)])
+def test_dense_update_on_the_lds_resident_kernel(dev, T, dims):
+    """The same on a graph dense enough for the LDS-resident kernel (forced: mode 3): a 64-column input runs as two 32-column
+    passes that ADD their products into a zeroed Y (two addends - bit-reproducible), narrower inputs as one pass that stores."""
+    import tcgnn_capi as c
+    import tcgnn_graph as G
+    din, dout = dims
+    rp, col = G.synthetic_csr(30000, 6_000_000, seed=3, device=dev)
+    n, E = rp.numel() - 1, col.numel()
+    bp = torch.zeros((n + 15) // 16, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+    T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+    meta = (rp, col, bp, e2c, e2r)
+    g = torch.Generator(device=dev).manual_seed(din + dout)
+    X = torch.randn(n, din, device=dev, generator=g); W = torch.randn(din, dout, device=dev, generator=g) / din ** 0.5
+    try:
+        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+        agg = T.forward(X, *meta)[0]
+        assert T.last_kernel(*meta) == "spmm_lds_kernel"
+        got = T.forward_gemm(X, W, *meta)[0]
+        assert T.last_kernel(*meta) == "spmm_lds_kernel"
+        got_r = T.forward_gemm(X, W, *meta, relu=True)[0]
+        again = T.forward_gemm(X, W, *meta)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    want = agg.double() @ W.double()
+    bound = agg.double().abs() @ W.double().abs() + 1.0
+    assert ((got.double() - want).abs() / bound).max().item() <= 4e-6
+    assert ((got_r.double() - want.clamp(min=0)).abs() / bound).max().item() <= 4e-6
+    assert torch.equal(got, again)
+    # the per-window gather walk gives the same product
+    c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+    try:
+        ref = T.forward_gemm(X, W, *meta)[0]
+        assert T.last_kernel(*meta) == "spmm_kernel"
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    assert ((got - ref).abs().double() / bound).max().item() <= 4e-6
+
+
+def test_gcn_layer_that_aggregates_first_trains_like_the_reference_order(dev, T):
+    """GCNConv(aggregate_first=True): (A X) W in one launch instead of A (X W).  Same matrix, rounded at a different point:
+    forward within the 1e-3 bar of the reference order, gradients from the unchanged backward pass identical in form
+    (G = A dY; dX = G W^T; dW = X^T G), and GIN takes the fused launch only when no gradient is asked for."""
+    import tcgnn_layers as L
+    rp, col = graphs.uniform_graph(3000, 150, seed=2)
+    _, meta = meta_for(dev, rp, col)
+    torch.manual_seed(0)
+    conv = L.GCNConv(64, 41).to(dev)
+    conv.weights.data.mul_(0.125)
+    x = torch.randn(3000, 64, device=dev)
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    ya = conv(xa, *meta)
+    yb = conv(xb, *meta, aggregate_first=True)
+    A = torch.zeros(3000, 3000, dtype=torch.float64, device=dev)
+    A[torch.from_numpy(np.repeat(np.arange(3000), np.diff(rp))).to(dev), meta[1].long()] = 1.0
+    exact = A @ (x.double() @ conv.weights.detach().double())
+    scale = A @ (x.double().abs() @ conv.weights.detach().double().abs()) + 1.0       # sum of |terms|: what 10-bit operand rounding is relative to
+    for y in (ya, yb):                                                          # either order is within operand rounding of the exact matrix
+        assert ((y.detach().double() - exact).abs() / scale).max().item() <= 2.0 ** -9
+    dY = torch.randn_like(ya)
+    ya.backward(dY); ga, gwa = xa.grad.clone(), conv.weights.grad.clone(); conv.weights.grad = None
+    yb.backward(dY)
+    assert torch.equal(ga, xb.grad) and torch.equal(gwa, conv.weights.grad)
+    gin = L.GINConv(64, 41).to(dev)
+    with torch.no_grad():
+        y_fused = gin(x, *meta)
+    assert T.last_kernel(*meta) in ("spmm_kernel", "spmm_lds_kernel")
+    y_two = gin(x.clone().requires_grad_(True), *meta)
+    assert ((y_fused - y_two).abs() / (y_two.abs() + 10.0)).max().item() <= 1e-5
+
+
+
 def _device_meta(dev, T, shape, seed=0):
     import tcgnn_graph as G
     n, nnz, _, _ = G.SHAPES[shape]
