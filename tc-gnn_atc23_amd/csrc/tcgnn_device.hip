@@ -93,6 +93,7 @@ struct tcgnn_plan {
     mutable std::vector<hipEvent_t> ev;
     mutable std::atomic<int> ev_used{0};
     mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
+    struct SdStream* sd = nullptr;   // metadata of the LDS-resident SDDMM (tcgnn_lds_sddmm.inc), built on its first call
 };
 
 // Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
@@ -864,6 +865,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
 }
 
 #include "tcgnn_lds_spmm.inc"
+#include "tcgnn_lds_sddmm.inc"
 
 // ------------------------------------------------------------------------------------------
 // SDDMM:  ef[e] = <X16[row e], X16[col e]>
@@ -2076,6 +2078,113 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     return TCGNN_OK;
 }
 
+// ---- LDS-resident SDDMM: eligibility, plan-time metadata, launch --------------------------------------------------------------
+// Measured on the Reddit shape at D = 64 (profiles/r02/sddmm_lds_*): pass 1 1.59 ms + pass 2 0.36 ms against 1.66 ms for the gather
+// walk - the compaction of each tile's ~26 real scores out of 512 products goes through the LDS pipeline (59 LDS cycles per
+// tile against 17 for the SpMM), which then is the bound.  Correct and tested, but not the default: TCGNN_SDDMM_LDS=1 or
+// tcgnn_set_spmm_mode(3) select it.
+static int g_sddmm_lds = [] { const char* e = getenv("TCGNN_SDDMM_LDS"); return e ? atoi(e) : 0; }();
+static int g_sd_dbg = [] { const char* e = getenv("TCGNN_SD_DBG"); return e ? atoi(e) : 0; }();
+static int sd_passes(int D) { return (round_up(D, 16) + 31) / 32; }
+// Taken when the SpMM time models pick the LDS-resident kernel for a 64-column matrix on this plan (the same cell stream, the
+// same streaming pattern), the rows are canonical, every offset fits its field, and the width is at most 8 passes.
+static bool sddmm_lds_eligible(const tcgnn_plan* p, int D) {
+    if (!(g_sddmm_lds || g_spmm_mode == 3) || !p || !p->canonical || p->nw_eff <= 0 || p->E < 1 || D < 1 || D > 256) return false;
+    if (p->sd && p->sd->built.load() < 0) return false;
+    if (g_spmm_mode == 1 || g_spmm_mode == 2 || g_spmm_mode == 4) return false;
+    if ((uint64_t)p->E * 4u >= (1ull << 32)) return false;                                       // 32-bit stream positions
+    if ((int64_t)((D + 15) / 16) * ((int64_t)p->Nc + 1) * 32 >= ((int64_t)1 << 32)) return false;   // the range filler's descriptor
+    return g_spmm_mode == 3 || lds_chosen(p, 64);
+}
+static size_t sd_partial_bytes(const tcgnn_plan* p, int D) {
+    return sddmm_lds_eligible(p, D) ? (((size_t)sd_passes(D) * (size_t)p->E * sizeof(float)) + 255) / 256 * 256 : 0;
+}
+
+__global__ void sd_max_window_kernel(const int32_t* __restrict__ rowptr, int32_t N, int32_t nw, uint32_t* out) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const int64_t r0 = (int64_t)w * kWinRows, r1 = r0 + kWinRows < N ? r0 + kWinRows : N;
+    atomicMax(out, (uint32_t)(rowptr[r1] - rowptr[r0]));
+}
+
+static int build_sddmm_stream(tcgnn_plan* p, hipStream_t stream) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!p->sd) p->sd = new (std::nothrow) SdStream();
+    if (!p->sd) return fail(TCGNN_ERR_OOM, "sddmm stream: host allocation failed");
+    SdStream& sd = *p->sd;
+    if (sd.built.load() != 0) return sd.built.load() > 0 ? TCGNN_OK : fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM unavailable on this plan");
+    constexpr int slot = lds_stream_of(2, kLdsMaxW2);
+    if (p->lds[slot].nranges <= 0) { const int rc = build_lds_cells(p, stream, slot); if (rc) { sd.built.store(-1); return rc; } }
+    const tcgnn_plan::CellStream& cs = p->lds[slot];
+    const int maxw = kLdsMaxW2, nranges = cs.nranges, nwg = cs.nwg;
+    const int64_t ntiles = cs.tiles, ngroups = (int64_t)nwg * nranges * kLdsWaves, ncell = ngroups * maxw;
+    uint32_t *d_cnt = nullptr, *d_gsize = nullptr, *d_tile_wr = nullptr, *d_max = nullptr;
+    int32_t* d_flags = nullptr;
+    auto bail = [&](int rc) {
+        (void)hipFree(d_cnt); (void)hipFree(d_gsize); (void)hipFree(d_tile_wr); (void)hipFree(d_max); (void)hipFree(d_flags);
+        (void)hipFree(sd.d_info); (void)hipFree(sd.d_cell_gpos); (void)hipFree(sd.d_gidx); (void)hipFree(sd.d_perm);
+        sd.d_info = nullptr; sd.d_cell_gpos = nullptr; sd.d_gidx = nullptr; sd.d_perm = nullptr;
+        sd.built.store(-1);   // the gather walk serves this plan from now on
+        return rc;
+    };
+    const size_t nt1 = (size_t)std::max<int64_t>(ntiles, 1);
+    hipError_t e = hipMalloc(&d_cnt, nt1 * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_gsize, (size_t)(ngroups + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_tile_wr, nt1 * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_max, 4);
+    if (e == hipSuccess) e = hipMalloc(&d_flags, 4);
+    if (e == hipSuccess) e = hipMalloc(&sd.d_info, nt1 * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc(&sd.d_cell_gpos, (size_t)(ncell + 1) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 4, stream);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "sddmm stream: %s", hipGetErrorString(e)));
+    if (ntiles > 0) hipLaunchKernelGGL(sd_tile_count_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, cs.d_cell_tiles, ntiles, d_cnt);
+    hipLaunchKernelGGL(sd_group_size_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, ngroups, maxw, d_gsize);
+    hipLaunchKernelGGL(sd_max_window_kernel, dim3((unsigned)((p->nw_eff + 255) / 256)), dim3(256), 0, stream, p->rowptr, p->N, p->nw_eff, d_max);
+    std::vector<uint32_t> gs((size_t)ngroups + 1);
+    uint32_t max_win = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(gs.data(), d_gsize, (size_t)ngroups * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&max_win, d_max, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "sddmm stream (sizes): %s", hipGetErrorString(e)));
+    uint64_t run = 0;
+    for (int64_t k = 0; k < ngroups; ++k) { const uint32_t c = gs[(size_t)k]; gs[(size_t)k] = (uint32_t)run; run += c; }
+    if (run >= (1ull << 32)) return bail(fail(TCGNN_ERR_UNSUPPORTED, "sddmm stream: %llu index bytes overflow 32 bits", (unsigned long long)run));
+    gs[(size_t)ngroups] = (uint32_t)run;
+    sd.perm32 = max_win > 65535u ? 1 : 0;
+    sd.max_window_edges = max_win;
+    const size_t b_gidx = (size_t)std::max<uint64_t>(run, 16), b_perm = (size_t)std::max<int64_t>(p->E, 1) * (sd.perm32 ? 4 : 2);
+    e = hipMalloc(&sd.d_gidx, b_gidx);
+    if (e == hipSuccess) e = hipMalloc(&sd.d_perm, b_perm);
+    if (e == hipSuccess) e = hipMemsetAsync(sd.d_gidx, 0, b_gidx, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gsize, gs.data(), (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "sddmm stream (%zu + %zu bytes): %s", b_gidx, b_perm, hipGetErrorString(e)));
+    hipLaunchKernelGGL(sd_group_fill_kernel, dim3((unsigned)((ngroups + 1 + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, d_gsize, ngroups, maxw,
+                       (uint32_t)run, sd.d_info, sd.d_cell_gpos);
+    hipLaunchKernelGGL(sd_window_base_kernel, dim3((unsigned)((p->nw_eff + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, p->d_order, p->rowptr,
+                       p->nw_eff, nwg, nranges, maxw, p->N, sd.d_info, d_tile_wr);
+    if (ntiles > 0) {
+        const int rows = lds_stream_buf_rows(slot) - 8;
+        if (sd.perm32) hipLaunchKernelGGL((sd_tile_fill_kernel<uint32_t>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, cs.d_cell_tiles, sd.d_info, d_tile_wr,
+                                          p->rowptr, p->col, ntiles, rows, p->N, sd.d_gidx, static_cast<uint32_t*>(sd.d_perm), d_flags);
+        else hipLaunchKernelGGL((sd_tile_fill_kernel<uint16_t>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, cs.d_cell_tiles, sd.d_info, d_tile_wr,
+                                p->rowptr, p->col, ntiles, rows, p->N, sd.d_gidx, static_cast<uint16_t*>(sd.d_perm), d_flags);
+    }
+    int32_t flag = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flags, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "sddmm stream (fill): %s", hipGetErrorString(e)));
+    if (flag) return bail(fail(TCGNN_ERR_BAD_GRAPH, "sddmm stream: a tile column has no CSR edge (metadata inconsistent with the CSR)"));
+    (void)hipFree(d_cnt); (void)hipFree(d_gsize); (void)hipFree(d_tile_wr); (void)hipFree(d_max); (void)hipFree(d_flags);
+    sd.bytes = nt1 * sizeof(uint4) + (size_t)(ncell + 1) * 4 + b_gidx + b_perm;
+    p->bytes += sd.bytes;
+    sd.built.store(1);
+    return TCGNN_OK;
+}
+
 static bool agnn_supported(const tcgnn_plan* plan, int32_t D) {
     return plan && plan->canonical && D >= 1 && D <= kMaxChunkDims && plan->E >= 8;
 }
@@ -2166,6 +2275,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
     for (auto& cs : plan->lds) { (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); }
+    if (plan->sd) { (void)hipFree(plan->sd->d_info); (void)hipFree(plan->sd->d_cell_gpos); (void)hipFree(plan->sd->d_gidx); (void)hipFree(plan->sd->d_perm); delete plan->sd; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -2337,7 +2447,8 @@ int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, in
 
 size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     if (!plan || D < 1) return 0;
-    return workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan);   // (the fused AGNN calls' reduction slots ride along)
+    // (the fused AGNN calls' reduction slots and the partial score streams of the LDS-resident SDDMM ride along)
+    return workspace_bytes_for(plan->Nc, D) + std::max(agnn_partial_bytes(plan), sd_partial_bytes(plan, D));
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
@@ -2407,6 +2518,39 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
+    // ---- LDS-resident column ranges (tcgnn_lds_sddmm.inc) where the time models pick that walk for this plan
+    bool lds = sddmm_lds_eligible(plan, D);
+    if (lds && !(plan->sd && plan->sd->built.load() > 0)) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) lds = false;   // (built by the next eager call)
+        else if (build_sddmm_stream(const_cast<tcgnn_plan*>(plan), stream) != TCGNN_OK) lds = false;
+    }
+    if (lds) {
+        const size_t image = workspace_bytes_for(plan->Nc, D), need = image + sd_partial_bytes(plan, D);
+        if (!ws || ws_bytes < need) return fail(TCGNN_ERR_WORKSPACE, "tcgnn_sddmm: workspace needs %zu bytes, got %zu", need, ws_bytes);
+        int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, /*planar=*/true);
+        if (rc) return rc;
+        const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(2, kLdsMaxW2)];
+        const SdStream& sd = *plan->sd;
+        float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + image);
+        const int npass = sd_passes(D);
+        SddmmLdsArgs l{cs.d_cell_ptr, sd.d_cell_gpos, cs.d_cell_tiles, sd.d_info, sd.d_gidx, plan->d_order, x16, part, plan->E,
+                       plan->N, plan->Nc, plan->row_off, dpad / 16, plan->Nc + 1, cs.nranges, plan->nw_eff, cs.nwg};
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)sddmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSdLdsBytes));
+            attr_set = true;
+        }
+        KernelTimer timer(plan, stream, "sddmm_lds_kernel");
+        hipLaunchKernelGGL(sddmm_lds_kernel, dim3((unsigned)cs.nwg, (unsigned)npass), dim3(kLdsWaves * 64), kSdLdsBytes, stream, l);
+        const int seg_cap = (int)std::min<uint32_t>((uint32_t)kSdFinishSeg, std::max<uint32_t>(256u, (sd.max_window_edges + 255u) & ~255u));
+        if (sd.perm32) hipLaunchKernelGGL((sddmm_finish_kernel<uint32_t>), dim3((unsigned)plan->nw_eff), dim3(512), (size_t)seg_cap * sizeof(float), stream, part, npass,
+                                          plan->E, plan->rowptr, static_cast<const uint32_t*>(sd.d_perm), hdr, plan->N, plan->nw_eff, d_ef, g_sd_dbg, seg_cap);
+        else hipLaunchKernelGGL((sddmm_finish_kernel<uint16_t>), dim3((unsigned)plan->nw_eff), dim3(512), (size_t)seg_cap * sizeof(float), stream, part, npass,
+                                plan->E, plan->rowptr, static_cast<const uint16_t*>(sd.d_perm), hdr, plan->N, plan->nw_eff, d_ef, g_sd_dbg, seg_cap);
+        HIP_TRY(hipGetLastError());
+        return TCGNN_OK;
+    }
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};

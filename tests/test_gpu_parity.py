@@ -376,6 +376,45 @@ def test_lds_resident_range_kernel_matches_oracle_and_plain_walk(dev, T, D, shap
     for mode in (1, 3):
         assert_parity(out[mode], ref, Y64, absY, "spmm mode %d" % mode)
 
+@pytest.mark.parametrize("D", [16, 32, 41, 64, 100, 128, 200])
+@pytest.mark.parametrize("shape", ["dense", "ragged", "very_dense", "empty_window"])
+def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
+    """The LDS-resident column-range SDDMM (tcgnn_lds_sddmm.inc: ranges of the planar image streamed into LDS, scores compacted
+    through a plan-time index into a window-major stream, second pass to CSR order; the automatic choice on Reddit-like graphs)
+    forced on graphs small enough for the oracle: several ranges, a ragged last window and range, hubs whose wavefront holds
+    more tiles / edges in one range than its pads (the per-tile slow path), half tiles with more than 64 edges (several
+    compaction rounds), a window without edges, 1 .. 7 passes of 32 columns with and without a zero plane at the end."""
+    import tcgnn_capi as c
+    if shape == "dense":
+        rp, col = graphs.uniform_graph(4100, 150, seed=21)
+    elif shape == "ragged":
+        rp, col = graphs.powerlaw_graph(2061, 9.0, seed=22)
+    elif shape == "very_dense":
+        rp, col = graphs.uniform_graph(1500, 700, seed=23)        # ~40 % dense: > 64 edges per half tile, > 512 index bytes per range
+    else:
+        rp, col = graphs.with_empty_window(*graphs.uniform_graph(2000, 60, seed=24), 32, 48)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 5)
+    X = (rng.standard_normal((n, D)) * float(rng.choice([0.02, 1.0, 50.0]))).astype(np.float32)
+    (tX,) = to_dev(dev, X)
+    out = {}
+    try:
+        for mode in (1, 3):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            out[mode] = T.forward_ef(tX, *meta)[0]
+            assert T.last_kernel(*meta) == ("sddmm_lds_kernel" if mode == 3 else ("sddmm_kernel" if D <= 128 else "sddmm_wide_kernel")), mode
+        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+        again = T.forward_ef(tX, *meta)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    assert torch.equal(out[3], again)                                        # deterministic
+    ef64, absef = O.sddmm_f64(X, rp, col)
+    ref = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    for mode in (1, 3):
+        assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
+
+
 @pytest.mark.parametrize("maxw", ["4", "8"])
 def test_lds_resident_range_kernel_with_one_layout_forced(maxw):
     """By default whole 64-column chunks run in the 8-windows-per-wavefront layout and the 1-3 planes left over in the
