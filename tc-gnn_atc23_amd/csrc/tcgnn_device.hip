@@ -82,6 +82,18 @@ struct tcgnn_plan {
         std::atomic<int32_t> nranges{0};
         int32_t nwg = 0;
         int64_t tiles = 0;
+        int32_t* d_order = nullptr;        // [nwg * 16 * maxw] window id of slot (workgroup, wavefront, window slot), -1 = none (lds_place_windows)
+        // hot (workgroup, range) pairs: the ranges a workgroup streams into LDS.  Pair k of the compact cell table belongs to
+        // workgroup wg for rbase[wg] <= k < rbase[wg + 1] and covers column range rlist[k].
+        int32_t npairs = 0;
+        int32_t* d_rbase = nullptr;        // [nwg + 1]
+        int32_t* d_rlist = nullptr;        // [npairs + 4]
+        // cold remainder: columns of the (workgroup, range) pairs too thin for a range fill, re-condensed per window in the gather
+        // walks' packed format; run by spmm_kernel, ADDING into what the LDS-resident kernel stored
+        int64_t cold_tiles = 0, hot_cols = 0, cold_cols = 0;
+        int64_t* d_cold_ptr = nullptr;     // [nw_eff + 1]
+        int32_t* d_cold_cols = nullptr;    // [cold_tiles][32]
+        uint32_t* d_cold_mask = nullptr;   // [cold_tiles][16]
         uint32_t* d_cell_ptr = nullptr;    // [nwg * nranges * 16 * maxw + 1] tile offset of cell (workgroup, range, wavefront, window slot)
         uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
     };
@@ -94,6 +106,7 @@ struct tcgnn_plan {
     mutable std::atomic<int> ev_used{0};
     mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
     struct SdStream* sd = nullptr;   // metadata of the LDS-resident SDDMM (tcgnn_lds_sddmm.inc), built on its first call
+    std::vector<int32_t> h_bp;       // blockPartition on the host: window weights for the placement of the LDS-resident walks
 };
 
 // Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
@@ -357,6 +370,7 @@ struct SpmmArgs {
     int32_t big;     // the fp16 image is 4 GB or more: gathers use 64-bit lane addresses (a buffer descriptor's index * stride wraps at 2^32)
     const float* w;  // f3: dense update fused behind the aggregation, Y[N, dout] = (A X) W with W [D, dout] fp32 row-major (nullptr: Y = A X)
     int32_t dout;
+    int32_t accumulate;   // Y += A X: the cold remainder of a plan whose dense part the LDS-resident kernel has already stored
 };
 
 // ---- f3: the dense update in the aggregation kernel's epilogue (gnn_conv.py:92-97: X' = TCGNN.forward(X); X' = mm(X', W)).
@@ -657,6 +671,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
     const int w = a.order[blockIdx.x];
     const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims; // first feature column of this pass
     const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
+    if (a.accumulate && !a.relu && tb == te) return;   // nothing to add to what the LDS-resident kernel stored
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
 
@@ -734,7 +749,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, v[ii] * inv1 * inv2);
+                    if (row0 + ii < a.N) {
+                        float* dst = a.y + (row0 + ii) * a.ldy + colg;
+                        *dst = relu_if(a.relu, v[ii] * inv1 * inv2 + (a.accumulate ? *dst : 0.0f));
+                    }
             }
         }
     } else {
@@ -744,7 +762,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(con
             if (colg < a.D) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, acc[s][ii] * inv1 * inv2);
+                    if (row0 + ii < a.N) {
+                        float* dst = a.y + (row0 + ii) * a.ldy + colg;
+                        *dst = relu_if(a.relu, acc[s][ii] * inv1 * inv2 + (a.accumulate ? *dst : 0.0f));
+                    }
             }
         }
     }
@@ -1762,7 +1783,9 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
                           const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr,
-                          int64_t ldx = 0, bool block_of_wider = false) {
+                          int64_t ldx = 0, bool block_of_wider = false, const uint32_t* hdr_from = nullptr) {
+    // hdr_from: the scale words of an image of the same matrix staged a moment ago (the planar one of a plan with a cold remainder):
+    // copied instead of recomputed, so both images are rounded with the same scale without a second pass over X
     const size_t need = workspace_bytes_for(plan->Nc, D);
     if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
         return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
@@ -1770,7 +1793,8 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
     const int dpad = round_up(D, 16);
     const int pitch = x16_pitch(dpad);
-    if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
+    if (hdr_from) { HIP_TRY(hipMemcpyAsync(hdr, hdr_from, 16, hipMemcpyDeviceToDevice, stream)); block_of_wider = true; }
+    else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
@@ -1884,52 +1908,210 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
     return yes;
 }
 
+// Window slots of a cell stream (order[cell_position(wg, wave, j)] = window id or -1): the windows, in their own order, are cut into
+// nwg contiguous blocks of about equal weight (blockPartition = condensed columns) and at most 16 x maxw windows; inside a block
+// they go heaviest-first to the least loaded wavefront that still has a free slot.
+static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
+static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order) {
+    const int nw = p->nw_eff, cap = kLdsWaves * maxw;
+    order.assign((size_t)nwg * cap, -1);
+    if (const char* env = getenv("TCGNN_LDS_PLACE")) {
+        if (!strcmp(env, "global")) {   // A/B aid: the r01 placement - windows heaviest first, dealt boustrophedon-wise over workgroups and wavefronts
+            std::vector<int32_t> idx((size_t)nw);
+            std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return p->h_bp[(size_t)x] > p->h_bp[(size_t)y]; });
+            for (int q = 0; q < nw; ++q) {
+                const int row = q / nwg, c = q % nwg;
+                const int wg = (row & 1) ? nwg - 1 - c : c, j = row / kLdsWaves, wv = row % kLdsWaves;
+                order[(size_t)cell_position(wg, (j & 1) ? kLdsWaves - 1 - wv : wv, j, maxw)] = idx[(size_t)q];
+            }
+            return;
+        }
+    }
+    // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
+    // ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
+    const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
+    auto weight = [&](int w) {
+        const double cols = 8.0 * std::max(p->h_bp[(size_t)w], 1);
+        return (int)std::ceil(cols / 32.0 + nranges_d * (1.0 - std::exp(-cols / nranges_d)));
+    };
+    double total = 0;
+    for (int w = 0; w < nw; ++w) total += weight(w);
+    std::vector<std::pair<int, int>> blk;   // (weight, window) of the block being dealt
+    double acc = 0;
+    int wg = 0;
+    auto deal = [&]() {
+        std::stable_sort(blk.begin(), blk.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+        int64_t load[kLdsWaves] = {0};
+        int used[kLdsWaves] = {0};
+        for (const auto& it : blk) {
+            int best = -1;
+            for (int v = 0; v < kLdsWaves; ++v)
+                if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
+            order[(size_t)cell_position(wg, best, used[best], maxw)] = it.second;
+            load[best] += it.first;
+            ++used[best];
+        }
+        blk.clear();
+    };
+    for (int w = 0; w < nw; ++w) {
+        const int wt = weight(w);
+        blk.emplace_back(wt, w);
+        acc += wt;
+        const int left = nw - (w + 1), wgs_left = nwg - (wg + 1);
+        const bool full = (int)blk.size() == cap;
+        const bool heavy_enough = acc >= total * (double)(wg + 1) / nwg;
+        if (wgs_left > 0 && (full || (heavy_enough && (int64_t)left <= (int64_t)wgs_left * cap))) { deal(); ++wg; }
+    }
+    if (!blk.empty()) deal();
+}
+
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (p->lds[slot].nranges > 0) return TCGNN_OK;
-    const int nw = p->nw_eff;
-    if (nw <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
+    if (p->nw_eff <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
     const int maxw = lds_stream_maxw(slot);
     const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
     const int nranges = (p->Nc + rows - 1) / rows;
     const int per_wg = kLdsWaves * maxw;
     const int nwg = lds_workgroups(p, maxw);
+    const int nw = nwg * per_wg;                              // window SLOTS of this stream
     const int64_t ncell = (int64_t)nwg * nranges * per_wg;
     uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
-    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); return rc; };
+    int32_t* d_sorder = nullptr;
+    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); (void)hipFree(d_sorder); return rc; };
+    std::vector<int32_t> sorder;
+    lds_place_windows(p, nwg, maxw, sorder);
     hipError_t e = hipMalloc(&d_cnt, (size_t)(ncell + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_sorder, sorder.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sorder, sorder.data(), sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     const int64_t nthreads = (int64_t)nw * nranges;
-    hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, nw, nwg,
+    hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, nw, nwg,
                        nranges, p->Nc, maxw, rows, d_cnt, d_firstq);
-    std::vector<uint32_t> cnt((size_t)ncell + 1);
+    // ---- hot / cold: a (workgroup, range) pair is worth a range fill only if enough of the workgroup's columns fall into it
+    const int64_t npairs_all = (int64_t)nwg * nranges;
+    uint32_t* d_paircols = nullptr;
+    int32_t *d_kmap = nullptr, *d_rbase = nullptr, *d_rlist = nullptr;
+    uint32_t* d_cellcols = d_cnt;   // (the dense table of step one holds columns per cell)
+    d_cnt = nullptr;
+    uint32_t* d_coldcols = nullptr;
+    int64_t* d_cold_ptr = nullptr;
+    int32_t* d_ccols = nullptr;
+    uint32_t* d_cmask = nullptr;
+    auto bail2 = [&](int rc) {
+        (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_rbase); (void)hipFree(d_rlist); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
+        (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask);
+        return bail(rc);
+    };
+    e = hipMalloc(&d_paircols, (size_t)npairs_all * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_kmap, (size_t)npairs_all * sizeof(int32_t));
+    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
+    hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, d_cellcols, npairs_all, per_wg, d_paircols);
+    std::vector<uint32_t> paircols((size_t)npairs_all);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(paircols.data(), d_paircols, paircols.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return bail2(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
+    // threshold: a range step costs a workgroup ~1.7 us (8-window layout, two passes over 256 CUs: ~13 ns of chip time) or
+    // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
+    // (mode 3: tests, timing) keeps every pair that holds a column; TCGNN_LDS_HOT_COLS overrides.
+    uint32_t hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
+    if (g_spmm_mode == 3) hot_min = 1u;
+    if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) hot_min = (uint32_t)std::max(1, atoi(env));
+    std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
+    int64_t hot_cols = 0, cold_cols = 0;
+    for (int wg = 0; wg < nwg; ++wg) {
+        rbase[(size_t)wg] = (int32_t)rlist.size();
+        for (int r = 0; r < nranges; ++r) {
+            const uint32_t c = paircols[(size_t)wg * nranges + r];
+            if (c >= hot_min) { kmap[(size_t)wg * nranges + r] = (int32_t)rlist.size(); rlist.push_back(r); hot_cols += c; }
+            else cold_cols += c;
+        }
+    }
+    rbase[(size_t)nwg] = (int32_t)rlist.size();
+    const int64_t npairs = (int64_t)rlist.size();
+    rlist.resize(rlist.size() + 4, 0);
+    const int64_t ncell_hot = npairs * per_wg;
+    e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rbase, rbase.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rlist, rlist.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell_hot + 1) * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_kmap, kmap.data(), kmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rbase, rbase.data(), rbase.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rlist, rlist.data(), rlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
+    if (ncell > 0) hipLaunchKernelGGL(cell_compact_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, npairs_all, per_wg, d_cnt);
+    std::vector<uint32_t> cnt((size_t)ncell_hot + 1);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
+    if (e != hipSuccess) return bail2(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
     uint64_t run = 0;
     for (size_t k = 0; k < cnt.size(); ++k) { const uint32_t c = cnt[k]; cnt[k] = (uint32_t)run; run += c; }
-    if (run >= (1ull << 32)) return bail(fail(TCGNN_ERR_BAD_GRAPH, "LDS-range SpMM: %llu tiles overflow the 32-bit cell table", (unsigned long long)run));
+    if (run >= (1ull << 32)) return bail2(fail(TCGNN_ERR_BAD_GRAPH, "LDS-range SpMM: %llu tiles overflow the 32-bit cell table", (unsigned long long)run));
     const int64_t ntiles = (int64_t)run;
     const int64_t nwords = std::max<int64_t>(ntiles, 1) * kCellWords;
     e = hipMalloc(&d_tiles, (size_t)nwords * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
+    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
     hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
-    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_order, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       maxw, rows, d_cnt, d_firstq, d_tiles);
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
+                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap);
     if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // `cnt` must outlive its copy
-    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
-    (void)hipFree(d_firstq);
-    p->lds[slot].d_cell_ptr = d_cnt; p->lds[slot].d_cell_tiles = d_tiles;
-    p->lds[slot].nwg = nwg; p->lds[slot].tiles = ntiles;
-    p->bytes += (size_t)(ncell + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t);
-    p->lds[slot].nranges = nranges;
+    // ---- the cold remainder, re-condensed per window for the gather walk
+    int64_t cold_tiles = 0;
+    size_t cold_bytes = 0;
+    if (e == hipSuccess && cold_cols > 0) {
+        const int nwe = p->nw_eff;
+        std::vector<uint32_t> coldc((size_t)nwe, 0);
+        e = hipMalloc(&d_coldcols, (size_t)nwe * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_coldcols, 0, (size_t)nwe * sizeof(uint32_t), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_coldcols);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(coldc.data(), d_coldcols, coldc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        std::vector<int64_t> cptr((size_t)nwe + 1, 0);
+        for (int w = 0; w < nwe; ++w) cptr[(size_t)w + 1] = cptr[(size_t)w] + (coldc[(size_t)w] + 31) / 32;
+        cold_tiles = cptr[(size_t)nwe];
+        const size_t b_ptr = cptr.size() * sizeof(int64_t), b_c = (size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols * 4, b_m = (size_t)std::max<int64_t>(cold_tiles, 1) * kWinRows * 4;
+        if (e == hipSuccess) e = hipMalloc(&d_cold_ptr, b_ptr);
+        if (e == hipSuccess) e = hipMalloc(&d_ccols, b_c);
+        if (e == hipSuccess) e = hipMalloc(&d_cmask, b_m);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_cold_ptr, cptr.data(), b_ptr, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cmask, 0, b_m, stream);
+        if (e == hipSuccess) {
+            // (padding columns of a window's last tile point at the all-zero sentinel row, like pack_kernel's)
+            std::vector<int32_t> fillv((size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols, p->Nc);
+            e = hipMemcpyAsync(d_ccols, fillv.data(), b_c, hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, d_kmap, nranges, p->Nc,
+                               maxw, rows, d_cold_ptr, d_ccols, d_cmask);
+            e = hipGetLastError();
+        }
+        cold_bytes = b_ptr + b_c + b_m;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // host vectors must outlive their copies
+    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
+    (void)hipFree(d_firstq); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
+    tcgnn_plan::CellStream& cs = p->lds[slot];
+    cs.d_order = d_sorder;
+    cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
+    cs.nwg = nwg; cs.tiles = ntiles;
+    cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
+    cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols;
+    cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
+    p->bytes += (size_t)(ncell_hot + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
+                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes;
+    cs.nranges = nranges;
     return TCGNN_OK;
 }
 
@@ -1967,6 +2149,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     // f3 on the LDS-resident kernel: one pass stores its product, the two 32-column passes of a 64-column matrix ADD theirs into a
     // zeroed Y (two addends: the sum does not depend on their order); wider inputs would need an ordered reduction - gather walk
     if (lds && d_W && !(round_up(D, 16) <= 64 && !g_lds_maxw)) lds = false;
+    if (lds && block_of_wider) lds = false;
     LdsPass passes[2]; int npass = 0;
     if (lds) {
         // every (layout, pass width) has its own cell stream, built the first time it is needed (plan creation builds the
@@ -1992,6 +2175,23 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                 if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0;
             }
         }
+    }
+    // ---- a plan with locality: the (workgroup, range) pairs too thin for a range fill were left out of the cell stream and sit
+    //      in a re-condensed remainder that the gather walk ADDS afterwards.  One stream must serve every pass of the call (the
+    //      remainder is per stream), the fused dense update cannot span two kernels, and a stream that kept less than half of the
+    //      columns is not worth its range fills at all.
+    const tcgnn_plan::CellStream* cold = nullptr;
+    if (lds) {
+        const tcgnn_plan::CellStream& c0 = plan->lds[lds_stream_of(passes[0].nt, passes[0].maxw)];
+        bool any_cold = false, thin = false;
+        for (int i = 0; i < npass; ++i) {
+            const tcgnn_plan::CellStream& ci = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
+            any_cold = any_cold || ci.cold_tiles > 0;
+            thin = thin || ci.hot_cols * 2 < ci.hot_cols + ci.cold_cols;
+        }
+        if (any_cold && (npass > 1 || d_W)) lds = false;
+        else if (thin && mode != 3) { lds = false; if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0; }
+        else if (any_cold) cold = &c0;
     }
     if (!lds && !pitch_fits_descriptor(D)) {
         // a row too long for the gather walks' buffer descriptor: independent column blocks, every one rounded
@@ -2037,17 +2237,36 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (relu) return fail(TCGNN_ERR_UNSUPPORTED, "tcgnn_spmm_gemm: ReLU cannot be fused when the product is accumulated over column passes");
             HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D_out * sizeof(float), stream));
         }
-        KernelTimer timer(plan, stream, "spmm_lds_kernel");
+        const _Float16* x16_rows = nullptr;
+        if (cold) {   // the remainder's gather walk reads the row-major image: staged behind the planar one, with its scale words
+            const size_t image = workspace_bytes_for(plan->Nc, D);
+            if (ws_bytes < 2 * image) return fail(TCGNN_ERR_WORKSPACE, "tcgnn_spmm: a plan with a cold remainder stages two images: %zu bytes, got %zu", 2 * image, ws_bytes);
+            const uint32_t* hdr2; int dpad2, pitch2;
+            const int rc = stage_features(plan, d_X, nullptr, D, static_cast<char*>(ws) + image, ws_bytes - image, stream, &hdr2, &x16_rows, &dpad2, &pitch2, false, d_gate, 0,
+                                          false, hdr);
+            if (rc) return rc;
+        }
+        KernelTimer timer(plan, stream, cold ? "spmm_lds_kernel + spmm_kernel (cold remainder)" : "spmm_lds_kernel");
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
-            SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, plan->d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
-                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, relu, d_W, D_out, accumulate};
+            SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate};
             HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
+        }
+        if (cold) {
+            const int pitch_r = x16_pitch(dpad);
+            // (the per-tile metadata DMA fetches 16 edge-offset words too; binary SpMM never looks at them: the mask array stands in)
+            SpmmArgs a{cold->d_cold_ptr, plan->d_order, cold->d_cold_cols, cold->d_cold_mask, reinterpret_cast<const int32_t*>(cold->d_cold_mask), x16_rows, nullptr, hdr, d_Y, plan->N, D, pitch_r, 0, plan->E,
+                       plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1};
+            const int waves = cold->cold_tiles >= (int64_t)6 * plan->nw_eff ? 4 : 1;
+            const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
+            if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(false, waves, 8, a, plan->nw_eff, nfull, stream)); }
+            if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(false, waves, rem, a, plan->nw_eff, 1, stream)); }
         }
         return TCGNN_OK;
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
-               image_is_big(plan->Nc, pitch), d_W, D_out};
+               image_is_big(plan->Nc, pitch), d_W, D_out, 0};
     if (d_W) a.ldy = D_out;
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -2117,8 +2336,9 @@ static int build_sddmm_stream(tcgnn_plan* p, hipStream_t stream) {
     constexpr int slot = lds_stream_of(2, kLdsMaxW2);
     if (p->lds[slot].nranges <= 0) { const int rc = build_lds_cells(p, stream, slot); if (rc) { sd.built.store(-1); return rc; } }
     const tcgnn_plan::CellStream& cs = p->lds[slot];
-    const int maxw = kLdsMaxW2, nranges = cs.nranges, nwg = cs.nwg;
-    const int64_t ntiles = cs.tiles, ngroups = (int64_t)nwg * nranges * kLdsWaves, ncell = ngroups * maxw;
+    if (cs.cold_cols > 0) { sd.built.store(-1); return fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM: the plan's cell stream leaves a cold remainder to the gather walk"); }
+    const int maxw = kLdsMaxW2, nwg = cs.nwg;
+    const int64_t ntiles = cs.tiles, ngroups = (int64_t)cs.npairs * kLdsWaves, ncell = ngroups * maxw;
     uint32_t *d_cnt = nullptr, *d_gsize = nullptr, *d_tile_wr = nullptr, *d_max = nullptr;
     int32_t* d_flags = nullptr;
     auto bail = [&](int rc) {
@@ -2163,8 +2383,9 @@ static int build_sddmm_stream(tcgnn_plan* p, hipStream_t stream) {
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "sddmm stream (%zu + %zu bytes): %s", b_gidx, b_perm, hipGetErrorString(e)));
     hipLaunchKernelGGL(sd_group_fill_kernel, dim3((unsigned)((ngroups + 1 + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, d_gsize, ngroups, maxw,
                        (uint32_t)run, sd.d_info, sd.d_cell_gpos);
-    hipLaunchKernelGGL(sd_window_base_kernel, dim3((unsigned)((p->nw_eff + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, p->d_order, p->rowptr,
-                       p->nw_eff, nwg, nranges, maxw, p->N, sd.d_info, d_tile_wr);
+    const int nslots = nwg * kLdsWaves * maxw;
+    hipLaunchKernelGGL(sd_window_base_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, cs.d_order, p->rowptr,
+                       nslots, cs.d_rbase, cs.d_rlist, maxw, p->N, sd.d_info, d_tile_wr);
     if (ntiles > 0) {
         const int rows = lds_stream_buf_rows(slot) - 8;
         if (sd.perm32) hipLaunchKernelGGL((sd_tile_fill_kernel<uint32_t>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, cs.d_cell_tiles, sd.d_info, d_tile_wr,
@@ -2274,7 +2495,10 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
-    for (auto& cs : plan->lds) { (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); }
+    for (auto& cs : plan->lds) {
+        (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
+        (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask);
+    }
     if (plan->sd) { (void)hipFree(plan->sd->d_info); (void)hipFree(plan->sd->d_cell_gpos); (void)hipFree(plan->sd->d_gidx); (void)hipFree(plan->sd->d_perm); delete plan->sd; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
@@ -2316,6 +2540,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         p->max_wb = std::max<int64_t>(p->max_wb, (bp[(size_t)w] + 3) / 4);
     }
     p->total_wb = wb_ptr[(size_t)nw];
+    p->h_bp.assign(bp.begin(), bp.begin() + nw);
     std::vector<int32_t> order((size_t)std::max(nw, 1));
     std::iota(order.begin(), order.begin() + nw, 0);
     std::stable_sort(order.begin(), order.begin() + nw, [&](int32_t x, int32_t y) { return bp[(size_t)x] > bp[(size_t)y]; });
@@ -2448,7 +2673,10 @@ int tcgnn_plan_read_timing(tcgnn_plan* plan, float* ms_out, int32_t capacity, in
 size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     if (!plan || D < 1) return 0;
     // (the fused AGNN calls' reduction slots and the partial score streams of the LDS-resident SDDMM ride along)
-    return workspace_bytes_for(plan->Nc, D) + std::max(agnn_partial_bytes(plan), sd_partial_bytes(plan, D));
+    // ... and the second (row-major) image of a plan whose LDS-resident walk leaves a cold remainder to the gather walk
+    const size_t image = workspace_bytes_for(plan->Nc, D);
+    const bool two_images = plan->nw_eff > 0 && (g_spmm_mode == 3 || (g_spmm_mode == 0 && lds_chosen(plan, round_up(D, 16))));
+    return image + std::max({agnn_partial_bytes(plan), sd_partial_bytes(plan, D), two_images ? image : (size_t)0});
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
@@ -2534,8 +2762,8 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         const SdStream& sd = *plan->sd;
         float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + image);
         const int npass = sd_passes(D);
-        SddmmLdsArgs l{cs.d_cell_ptr, sd.d_cell_gpos, cs.d_cell_tiles, sd.d_info, sd.d_gidx, plan->d_order, x16, part, plan->E,
-                       plan->N, plan->Nc, plan->row_off, dpad / 16, plan->Nc + 1, cs.nranges, plan->nw_eff, cs.nwg};
+        SddmmLdsArgs l{cs.d_cell_ptr, sd.d_cell_gpos, cs.d_cell_tiles, sd.d_info, sd.d_gidx, cs.d_order, x16, part, plan->E,
+                       plan->N, plan->Nc, plan->row_off, dpad / 16, plan->Nc + 1, cs.nranges, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist};
         static bool attr_set = false;
         if (!attr_set) {
             HIP_TRY(hipFuncSetAttribute((const void*)sddmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSdLdsBytes));

@@ -415,6 +415,53 @@ def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
         assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
 
 
+@pytest.mark.parametrize("D", [16, 48, 64, 96, 128])
+def test_lds_resident_walk_with_a_cold_remainder(dev, T, D, monkeypatch):
+    """A graph with communities: the (workgroup, column range) pairs that hold few of a workgroup's columns are left out of the
+    LDS-resident cell stream and go, re-condensed, to the gather walk, which ADDS its part to what the LDS-resident kernel
+    stored.  Forced here (mode 3 + a threshold that splits this small graph): hot and cold parts both non-empty, several
+    workgroups with different range lists, ReLU applied once on the sum, the gated staging on both images; against the
+    oracle and the per-window gather walk."""
+    import tcgnn_capi as c
+    rng = np.random.default_rng(77)
+    n, blocks = 6144, 6
+    size = n // blocks
+    src_in = rng.integers(0, n, size=380000); dst_in = (src_in // size) * size + rng.integers(0, size, size=380000)
+    src_out = rng.integers(0, n, size=30000); dst_out = rng.integers(0, n, size=30000)
+    src = np.concatenate([src_in, src_out]); dst = np.concatenate([dst_in, dst_out])
+    rp, col = graphs.csr_from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), n)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    (tX,) = to_dev(dev, X)
+    monkeypatch.setenv("TCGNN_LDS_HOT_COLS", "600")
+    T.clear_plan_cache()
+    try:
+        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+        Y = T.forward(tX, *meta)[0]
+        kernel = T.last_kernel(*meta)
+        Yr = T.forward_fused(tX, *meta, relu=True)[0]
+        Yg = T.forward_fused(tX, *meta, gate=Y)[0]
+        again = T.forward(tX, *meta)[0]
+        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+        Y1 = T.forward(tX, *meta)[0]
+        Yg1 = T.forward_fused(tX, *meta, gate=Y)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        monkeypatch.delenv("TCGNN_LDS_HOT_COLS")
+        T.clear_plan_cache()
+    if D in (16, 48, 64, 128):                      # one cell stream serves every pass: the split path
+        assert kernel == "spmm_lds_kernel + spmm_kernel (cold remainder)", kernel
+    else:                                           # 64 + 32 columns use two streams: the call takes the gather walk
+        assert kernel in ("spmm_kernel", "spmm_blocked_kernel"), kernel
+    assert torch.equal(Y, again)
+    Y64, absY = O.spmm_f64(X, rp, col)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(Y.cpu().numpy(), ref, Y64, absY, "spmm hot + cold")
+    assert_parity(Y1.cpu().numpy(), ref, Y64, absY, "spmm gather")
+    assert torch.equal(Yr, torch.relu(Y))
+    assert ((Yg - Yg1).abs() / (torch.from_numpy(absY).to(dev) + 1.0)).max().item() <= TIGHT
+
+
 @pytest.mark.parametrize("maxw", ["4", "8"])
 def test_lds_resident_range_kernel_with_one_layout_forced(maxw):
     """By default whole 64-column chunks run in the 8-windows-per-wavefront layout and the 1-3 planes left over in the
