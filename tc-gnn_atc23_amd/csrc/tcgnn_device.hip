@@ -2258,7 +2258,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             // (the per-tile metadata DMA fetches 16 edge-offset words too; binary SpMM never looks at them: the mask array stands in)
             SpmmArgs a{cold->d_cold_ptr, plan->d_order, cold->d_cold_cols, cold->d_cold_mask, reinterpret_cast<const int32_t*>(cold->d_cold_mask), x16_rows, nullptr, hdr, d_Y, plan->N, D, pitch_r, 0, plan->E,
                        plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1};
-            const int waves = cold->cold_tiles >= (int64_t)6 * plan->nw_eff ? 4 : 1;
+            static const int cold_w4 = [] { const char* e = getenv("TCGNN_COLD_W4"); return e ? atoi(e) : 48; }();   // tiles per window from which 4 wavefronts share it (SBM Reddit shape, 25 cold tiles per window: 169 us with one wavefront, 202 with four)
+            const int waves = cold->cold_tiles >= (int64_t)cold_w4 * plan->nw_eff ? 4 : 1;
             const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
             if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(false, waves, 8, a, plan->nw_eff, nfull, stream)); }
             if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(false, waves, rem, a, plan->nw_eff, 1, stream)); }
