@@ -1911,12 +1911,22 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
 // Window slots of a cell stream (order[cell_position(wg, wave, j)] = window id or -1): the windows, in their own order, are cut into
 // nwg contiguous blocks of about equal weight (blockPartition = condensed columns) and at most 16 x maxw windows; inside a block
 // they go heaviest-first to the least loaded wavefront that still has a free slot.
+static bool lds_place_global(const tcgnn_plan* p) {
+    if (const char* env = getenv("TCGNN_LDS_PLACE")) return !strcmp(env, "global");
+    int64_t mx = 0;
+    for (int w = 0; w < p->nw_eff; ++w) mx = std::max<int64_t>(mx, p->h_bp[(size_t)w]);
+    return mx * p->nw_eff > 4 * std::max<int64_t>(p->tc_blocks, 1);
+}
 static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
 static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order) {
     const int nw = p->nw_eff, cap = kLdsWaves * maxw;
     order.assign((size_t)nwg * cap, -1);
-    if (const char* env = getenv("TCGNN_LDS_PLACE")) {
-        if (!strcmp(env, "global")) {   // A/B aid: the r01 placement - windows heaviest first, dealt boustrophedon-wise over workgroups and wavefronts
+    // Hub windows (power-law graphs numbered by degree) sit next to each other: a contiguous block of them fills a few wavefronts of
+    // its workgroup and leaves the rest idle, so the workgroup runs several times longer than the mean (R-MAT, Reddit shape: 1.20 ms
+    // against 0.85 ms).  When the heaviest window is far above the mean the windows are instead dealt heaviest first, boustrophedon-wise
+    // over workgroups and wavefronts - every workgroup gets one hub and a share of the light windows.  TCGNN_LDS_PLACE=global|local forces it.
+    {
+        if (lds_place_global(p)) {
             std::vector<int32_t> idx((size_t)nw);
             std::iota(idx.begin(), idx.end(), 0);
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return p->h_bp[(size_t)x] > p->h_bp[(size_t)y]; });
@@ -2020,7 +2030,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
     // (mode 3: tests, timing) keeps every pair that holds a column; TCGNN_LDS_HOT_COLS overrides.
     uint32_t hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
-    if (g_spmm_mode == 3) hot_min = 1u;
+    if (g_spmm_mode == 3 || lds_place_global(p)) hot_min = 1u;   // (the dealt placement has no locality to split on: every pair holds about the same share)
     if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) hot_min = (uint32_t)std::max(1, atoi(env));
     std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
     int64_t hot_cols = 0, cold_cols = 0;
@@ -2545,6 +2555,23 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     std::vector<int32_t> order((size_t)std::max(nw, 1));
     std::iota(order.begin(), order.begin() + nw, 0);
     std::stable_sort(order.begin(), order.begin() + nw, [&](int32_t x, int32_t y) { return bp[(size_t)x] > bp[(size_t)y]; });
+    // Block -> window map of the per-window gather walks.  Heaviest first keeps a hub window from starting last; but when no window
+    // is far above the mean the order is free, and then locality decides: workgroup b runs on XCD b % 8 (observed dispatch, used for
+    // speed only), so XCD x takes the x-th contiguous eighth of the windows in their own order - the workgroups resident on one
+    // XCD at one time are neighbours in the graph's numbering and share their gathered rows in that XCD's L2 (communities).
+    {
+        int64_t mx = 0;
+        for (int w = 0; w < nw; ++w) mx = std::max<int64_t>(mx, bp[(size_t)w]);
+        static const int order_mode = [] { const char* e = getenv("TCGNN_ORDER"); return e ? atoi(e) : 0; }();   // 0 automatic, 1 heaviest first, 2 XCD-contiguous
+        const bool balanced = nw > 0 && mx * nw <= 4 * std::max<int64_t>(p->tc_blocks, 1);
+        if (order_mode == 2 || (order_mode == 0 && balanced && nw >= 64)) {
+            const int q = nw / 8, r = nw % 8;
+            for (int b = 0; b < nw; ++b) {
+                const int xcd = b % 8, idx = b / 8;
+                order[(size_t)b] = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+            }
+        }
+    }
     p->waves = (nw > 0 && p->total_wb >= (int64_t)6 * nw) ? 4 : 1;
 
     const size_t n_wb = (size_t)std::max<int64_t>(p->total_wb, 1);
