@@ -488,7 +488,7 @@ static constexpr int kPadBytes = 256;
 template <int NT, bool VAL>
 struct TileWalker {
     static constexpr int TILE_BYTES = NT * 1024;
-    static constexpr int WAVE_LDS = 2 * TILE_BYTES + kPadBytes + (VAL ? 1024 : 0);  // two tile buffers, metadata pad, edge values
+    static constexpr int WAVE_LDS = 2 * TILE_BYTES + kPadBytes + (VAL ? 2048 : 0);  // two tile buffers, metadata pad, edge values (2 x 4 per lane)
     static constexpr int NIDS = NT + 1 + (VAL ? 1 : 0);
     using Img = TileImage<NT>;
     const SpmmArgs& a;
@@ -532,9 +532,10 @@ struct TileWalker {
         }
     }
 
-    struct Cur {            // the tile being multiplied: its mask word, edge offset, value-window shift
+    struct Cur {            // the tile being multiplied: its mask word, edge offset, value-window shift; wide: eight values fetched
         uint32_t m, eb;
         int shift;
+        bool wide;
     };
     template <int BUF> __device__ __forceinline__ void dma_gather(const uint32_t* cid) const {
         if (a.big) {   // (wave-uniform: a kernel argument)
@@ -551,25 +552,39 @@ struct TileWalker {
             __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16,
                                                         (int)cid[k], (int)doff[k], 0, 0, 0);
     }
-    // edge values of this lane's byte of row i: 4 consecutive floats starting at the first edge of
-    // the byte, clamped so the read stays inside edge_val; lands in this lane's slot of the value pad
+    // edge values of this lane's byte of row i: consecutive floats starting at the first edge of the byte (a row's edges inside
+    // eight columns are one run of the CSR), clamped so the read stays inside edge_val; they land in this lane's slot of the value
+    // pad.  Four cover the run almost always; when some lane's run is longer (hub rows: every second column is an edge) a second
+    // DMA fetches the next four - wave-uniform, decided from the mask.
     __device__ __forceinline__ void dma_vals(Cur& c) const {
         const int64_t e0 = (int64_t)c.eb + __popc(c.m & ((1u << (8 * g)) - 1u));
-        int64_t lo = e0 < a.E - 4 ? e0 : a.E - 4;
+        int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
         if (lo < 0) lo = 0;
         c.shift = (int)(e0 - lo);
+        c.wide = a.E >= 8 && __any(__popc((c.m >> (8 * g)) & 0xffu) + c.shift > 4);
         __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo), (LDS_AS void*)(uintptr_t)vpad, 16, 0, 0);
+        if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo + 4), (LDS_AS void*)(uintptr_t)(vpad + 1024u), 16, 0, 0);
     }
 
-    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, floatx4 (&acc)[NT]) const {
+    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, const uintx4& q2, floatx4 (&acc)[NT]) const {
         half8 af;
         if constexpr (VAL) {
             const uint32_t mb = (cur.m >> (8 * g)) & 0xffu;
             const floatx4 vals = __builtin_bit_cast(floatx4, q);
             const int nb = __popc(mb);
-            if (__builtin_expect(__any(nb + cur.shift > 4), 0)) {
-                // rare: more than four edges of one row inside 8 columns, or the clamp at the end of
-                // edge_val; ordinary loads (the compiler drains the DMA queue for them)
+            if (cur.wide) {
+                const floatx4 vals2 = __builtin_bit_cast(floatx4, q2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = __popc(mb & ((1u << j) - 1u)) + cur.shift;
+                    const floatx4 sv = (k & 4) ? vals2 : vals;
+                    const float v01 = (k & 1) ? sv[1] : sv[0];
+                    const float v23 = (k & 1) ? sv[3] : sv[2];
+                    const float v = (k & 2) ? v23 : v01;
+                    af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
+                }
+            } else if (__builtin_expect(__any(nb + cur.shift > 4), 0)) {
+                // (fewer than eight edges in the whole matrix) ordinary loads; the compiler drains the DMA queue for them
                 const int64_t e0 = (int64_t)cur.eb + __popc(cur.m & ((1u << (8 * g)) - 1u));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -612,11 +627,16 @@ struct TileWalker {
         uintx4 q;
         const uint32_t qaddr = VAL ? vpad + (uint32_t)lane * 16u : atab + (((cur.m >> (8 * g)) & 0xffu) << 4);
         lds_ids_block<NIDS>(idaddr, v, qaddr, q);
+        uintx4 q2 = q;
+        if constexpr (VAL) {
+            if (cur.wide) { const uint32_t qa2 = qaddr + 1024u; lds_q_block<1, 0>(&qa2, &q2); }   // (before the next tile's values overwrite the pad)
+        }
         const bool more = tn < te;
         Cur nx;
         nx.m = v[NT];
         nx.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
         nx.shift = 0;
+        nx.wide = false;
         const int64_t tnn = tn + step;
         if (more) {
             dma_gather<BUF ^ 1>(v);
@@ -624,7 +644,7 @@ struct TileWalker {
             const int64_t tf = tnn < te ? tnn : t_after;   // metadata two tiles ahead; at the end of the run: the caller's next run
             if (tf >= 0) meta.dma(tf, pad);
         }
-        multiply<BUF>(cur, q, acc);
+        multiply<BUF>(cur, q, q2, acc);
         cur = nx;
         t = tn;
         tn = tnn;
@@ -646,6 +666,7 @@ struct TileWalker {
         cur.m = v[NT];
         cur.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
         cur.shift = 0;
+        cur.wide = false;
         dma_gather<0>(v);
         if constexpr (VAL) dma_vals(cur);
         int64_t tn = t + step;
@@ -1324,6 +1345,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         auto dma_vals = [&](Cur& c) {
             const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & low8);
             int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
+            if (lo < 0) lo = 0;
             c.sh = (int)(e0 - lo);
             c.wide = __any(__popc((c.m >> (8 * g)) & 0xffu) + c.sh > 4);
             __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)aux, 16, 0, 0);
