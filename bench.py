@@ -262,6 +262,12 @@ def single_gpu(args):
             leg = timed_leg(m_, E_, lambda: TCGNN.forward(X_, *m_), spmm_bytes(n_, E_, d), reps=10)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
             row["spmm"] = leg
+        if "spmm_val" in ops:
+            att_ = torch.randn(1, E_, device=dev, generator=g)
+            leg = timed_leg(m_, E_, lambda: TCGNN.forward_AGNN(X_, rp_, col_, att_, bp_, e2c_, e2r_), spmm_bytes(n_, E_, d) + 4 * E_, reps=10)
+            leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
+            row["spmm_val"] = leg
+            del att_
         if "sddmm" in ops:
             leg = timed_leg(m_, E_, lambda: TCGNN.forward_ef(X_, *m_), sddmm_bytes(n_, E_, d), reps=10)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
@@ -349,10 +355,11 @@ def single_gpu(args):
                           **{k: out["roofline"][k] for k in ("traffic", "mfma_busy", "mfma_useful_frac", "mfma_useful_tflops", "mfma_peak_frac")}}}]
     if not args.no_extra and args.scale == 1.0:
         TCGNN.clear_plan_cache()
-        for shape, gen, d, ops in ((args.shape, "sbm", D, ("spmm", "sddmm")), (args.shape, "rmat", D, ("spmm", "sddmm")),
-                                   ("ogbn-products", "uniform", 128, ("spmm", "sddmm", "agnn", "agnn_epoch")),
-                                   ("ogbn-products", "sbm", 128, ("spmm", "sddmm", "agnn")),
-                                   ("ogbn-products", "rmat", 128, ("spmm", "sddmm"))):
+        every = ("spmm", "spmm_val", "sddmm", "agnn")
+        for shape, gen, d, ops in ((args.shape, "sbm", D, every), (args.shape, "rmat", D, every),
+                                   ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
+                                   ("ogbn-products", "sbm", 128, every),
+                                   ("ogbn-products", "rmat", 128, every)):
             try:
                 datasets.append(dataset_legs(shape, gen, d, ops, args.seed))
             except Exception as exc:   # an extra dataset must never take the headline down

@@ -2140,6 +2140,12 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
     cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols;
+    static const bool verbose = [] { const char* e = getenv("TCGNN_VERBOSE"); return e && atoi(e) > 0; }();
+    if (verbose)
+        fprintf(stderr, "[tcgnn] cell stream %d (%d windows per wavefront, %d-row ranges): %d workgroups x %d ranges, %lld of %lld pairs hot (>= %u columns), "
+                        "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
+                slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
+                (long long)ntiles, (long long)cold_tiles, lds_place_global(p) ? "dealt" : "contiguous blocks");
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
     p->bytes += (size_t)(ncell_hot + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
                 (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes;

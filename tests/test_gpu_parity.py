@@ -64,6 +64,7 @@ CASES = [(n, rp, c) for n, rp, c in graphs.edge_case_graphs()]
 CASES.append(("citeseer_shape", *graphs.uniform_graph(3327, 2.8, seed=1)))
 CASES.append(("dense_n3000_deg150", *graphs.uniform_graph(3000, 150, seed=2)))     # 4 wavefronts per window
 CASES.append(("powerlaw_n12000_deg40", *graphs.powerlaw_graph(12000, 40, seed=3)))  # skewed window lengths
+CASES.append(("hub_rows_n2500", *graphs.hub_rows_graph(2500, seed=77)))             # runs of more than four edges inside eight columns
 
 
 def test_hardware_contracts_probe():
@@ -113,6 +114,29 @@ def test_three_kernels_match_oracle(dev, T, case, D):
     assert len(ef) == 1 and ef[0].shape == (nnz,) and ef[0].dtype == torch.float32
     ef64, absef = O.sddmm_f64(X, rp, col)
     assert_parity(ef[0].cpu().numpy(), O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32), ef64, absef, "sddmm", unit)
+
+
+def test_edge_valued_spmm_on_hub_rows_with_runs_longer_than_four(dev, T):
+    """Rows that are edges to (nearly) every column: a lane's run of values inside its eight tile columns is up to eight long
+    and takes the second value fetch of TileWalker::dma_vals (TCGNN_kernel.cu:459-578 gathers value by value); every gather walk."""
+    rp, col = graphs.hub_rows_graph(2500, seed=77)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    rng = np.random.default_rng(78)
+    import tcgnn_capi as c
+    for D in (64, 41):
+        X = rng.standard_normal((n, D)).astype(np.float32)
+        att = rng.standard_normal(nnz).astype(np.float32)
+        tX, tatt = to_dev(dev, X, att)
+        Yv64, absYv = O.spmm_f64(X, rp, col, att)
+        Yref = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+        try:
+            for mode in (0, 1, 2):
+                c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+                Yv = T.forward_AGNN(tX, trp, tcol, tatt.view(1, -1), tbp, te2c, te2r)[0]
+                assert_parity(Yv.cpu().numpy(), Yref, Yv64, absYv, "spmm_val hub rows, mode %d" % mode, True)
+        finally:
+            c.lib.tcgnn_set_spmm_mode(0)
 
 
 @pytest.mark.parametrize("D", [16, 64, 41, 128, 160])
@@ -293,7 +317,7 @@ def test_layers_with_hip_kernels_reproduce_reference_fixture(dev, T):
 
 
 FUSED_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n40", "empty_middle_window_n48", "powerlaw_n1000", "citeseer_shape",
-                                            "dense_n3000_deg150", "powerlaw_n12000_deg40")]
+                                            "dense_n3000_deg150", "powerlaw_n12000_deg40", "hub_rows_n2500")]
 
 
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
