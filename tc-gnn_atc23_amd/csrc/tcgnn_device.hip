@@ -91,6 +91,8 @@ struct tcgnn_plan {
         // cold remainder: columns of the (workgroup, range) pairs too thin for a range fill, re-condensed per window in the gather
         // walks' packed format; run by spmm_kernel, ADDING into what the LDS-resident kernel stored
         int64_t cold_tiles = 0, hot_cols = 0, cold_cols = 0;
+        uint32_t* d_parts = nullptr;       // [slots] split windows: part | parts << 8 | LDS scratch index << 16 (nullptr: no window is split)
+        int32_t nsplit = 0;                // windows shared by several wavefronts of their workgroup
         int64_t* d_cold_ptr = nullptr;     // [nw_eff + 1]
         int32_t* d_cold_cols = nullptr;    // [cold_tiles][32]
         uint32_t* d_cold_mask = nullptr;   // [cold_tiles][16]
@@ -107,6 +109,7 @@ struct tcgnn_plan {
     mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
     struct SdStream* sd = nullptr;   // metadata of the LDS-resident SDDMM (tcgnn_lds_sddmm.inc), built on its first call
     std::vector<int32_t> h_bp;       // blockPartition on the host: window weights for the placement of the LDS-resident walks
+    mutable std::atomic<int> lds_extra[2] = {{-1}, {-1}};   // window slots the split hub windows add (4 / 8 windows per wavefront); -1: not computed
 };
 
 // Brackets the dominant kernel (spmm / sddmm proper, not the staging pass) with HIP events on the
@@ -1868,12 +1871,58 @@ static int lds_passes(int dpad, LdsPass (&passes)[2]) {
 }
 // workgroups of one pass: enough to hold every window, spread over every CU a pass can have (with 8 windows per wavefront a
 // 64-column chunk takes two passes, hence half the CUs each)
-static int lds_workgroups(const tcgnn_plan* p, int maxw) {
+static bool lds_place_global(const tcgnn_plan* p) {
+    if (const char* env = getenv("TCGNN_LDS_PLACE")) return !strcmp(env, "global");
+    int64_t mx = 0;
+    for (int w = 0; w < p->nw_eff; ++w) mx = std::max<int64_t>(mx, p->h_bp[(size_t)w]);
+    return mx * p->nw_eff > 4 * std::max<int64_t>(p->tc_blocks, 1);
+}
+static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
+// weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
+// ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
+static double lds_window_weight(const tcgnn_plan* p, int w, double nranges_d) {
+    const double cols = 8.0 * std::max(p->h_bp[(size_t)w], 1);
+    return std::ceil(cols / 32.0 + nranges_d * (1.0 - std::exp(-cols / nranges_d)));
+}
+static int lds_workgroups_unsplit(const tcgnn_plan* p, int maxw, int extra_slots) {
     const int per_wg = kLdsWaves * maxw;
-    int nwg = (p->nw_eff + per_wg - 1) / per_wg;
+    const int64_t slots = (int64_t)p->nw_eff + extra_slots;
+    int nwg = (int)((slots + per_wg - 1) / per_wg);
     const int cu_target = maxw == kLdsMaxW2 ? std::max(1, p->num_cus / 2) : p->num_cus;
     if (nwg < cu_target) nwg = std::max(nwg, std::min(cu_target, (p->nw_eff + kLdsWaves - 1) / kLdsWaves));
     return nwg;
+}
+// Hub windows: a wavefront owns whole windows, so a window whose tiles exceed a wavefront's fair share of the workgroup's work
+// is the critical path of every range (R-MAT, Reddit shape: the window of the sixteen top hubs holds 3.6 wavefront shares).
+// Such a window is SPLIT: k wavefronts of one workgroup each take every k-th run of its tiles in every range and their partial
+// sums are added through LDS, in a fixed order, at the end of the kernel.  parts[w] = k (1: whole).  Only on graphs that take the
+// dealt placement (lds_place_global); TCGNN_LDS_SPLIT=0 switches it off.
+static constexpr int kLdsMaxParts = 8, kLdsMaxFollowers = 32;   // (followers of a workgroup: 32 x NT KB of LDS scratch)
+static int lds_split_parts(const tcgnn_plan* p, int maxw, std::vector<uint8_t>* parts) {
+    static const int enabled = [] { const char* e = getenv("TCGNN_LDS_SPLIT"); return e ? atoi(e) : 1; }();
+    const int nw = p->nw_eff;
+    if (parts) parts->assign((size_t)nw, 1);
+    if (!enabled || nw <= 0 || !lds_place_global(p)) return 0;
+    const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
+    double total = 0;
+    for (int w = 0; w < nw; ++w) total += lds_window_weight(p, w, nranges_d);
+    const double share = total / ((double)lds_workgroups_unsplit(p, maxw, 0) * kLdsWaves);
+    int extra = 0;
+    for (int w = 0; w < nw; ++w) {
+        const double wt = lds_window_weight(p, w, nranges_d);
+        if (wt <= 1.5 * share) continue;
+        const int k = (int)std::min<double>(kLdsMaxParts, std::ceil(wt / share));
+        if (k < 2) continue;
+        if (parts) (*parts)[(size_t)w] = (uint8_t)k;
+        extra += k - 1;
+    }
+    return extra;
+}
+static int lds_workgroups(const tcgnn_plan* p, int maxw) {
+    const int which = maxw == kLdsMaxW2 ? 1 : 0;
+    int extra = p->lds_extra[which].load(std::memory_order_relaxed);
+    if (extra < 0) { extra = lds_split_parts(p, maxw, nullptr); p->lds_extra[which].store(extra, std::memory_order_relaxed); }
+    return lds_workgroups_unsplit(p, maxw, extra);
 }
 
 // Kernel-time models behind the automatic choice between the LDS-resident kernel and the gather walks, microseconds on
@@ -1933,22 +1982,19 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
 // Window slots of a cell stream (order[cell_position(wg, wave, j)] = window id or -1): the windows, in their own order, are cut into
 // nwg contiguous blocks of about equal weight (blockPartition = condensed columns) and at most 16 x maxw windows; inside a block
 // they go heaviest-first to the least loaded wavefront that still has a free slot.
-static bool lds_place_global(const tcgnn_plan* p) {
-    if (const char* env = getenv("TCGNN_LDS_PLACE")) return !strcmp(env, "global");
-    int64_t mx = 0;
-    for (int w = 0; w < p->nw_eff; ++w) mx = std::max<int64_t>(mx, p->h_bp[(size_t)w]);
-    return mx * p->nw_eff > 4 * std::max<int64_t>(p->tc_blocks, 1);
-}
-static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
-static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order) {
+static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit) {
     const int nw = p->nw_eff, cap = kLdsWaves * maxw;
     order.assign((size_t)nwg * cap, -1);
+    parts_out.clear();
+    nsplit = 0;
     // Hub windows (power-law graphs numbered by degree) sit next to each other: a contiguous block of them fills a few wavefronts of
     // its workgroup and leaves the rest idle, so the workgroup runs several times longer than the mean (R-MAT, Reddit shape: 1.20 ms
     // against 0.85 ms).  When the heaviest window is far above the mean the windows are instead dealt heaviest first, boustrophedon-wise
     // over workgroups and wavefronts - every workgroup gets one hub and a share of the light windows.  TCGNN_LDS_PLACE=global|local forces it.
-    {
-        if (lds_place_global(p)) {
+    if (lds_place_global(p)) {
+        std::vector<uint8_t> k;
+        const int extra = lds_split_parts(p, maxw, &k);
+        if (extra == 0) {
             std::vector<int32_t> idx((size_t)nw);
             std::iota(idx.begin(), idx.end(), 0);
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return p->h_bp[(size_t)x] > p->h_bp[(size_t)y]; });
@@ -1959,14 +2005,64 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
             }
             return;
         }
+        // With split windows: longest-processing-time placement.  Windows (a split one with all its parts) go heaviest first to the
+        // least loaded workgroup that has the slots; inside a workgroup the items (whole windows and parts) go heaviest first to
+        // the least loaded wavefront with a free slot, the parts of one window to different wavefronts.
+        const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
+        std::vector<double> wt((size_t)nw);
+        for (int w = 0; w < nw; ++w) wt[(size_t)w] = lds_window_weight(p, w, nranges_d);
+        std::vector<int32_t> idx((size_t)nw);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
+        std::vector<double> wg_load((size_t)nwg, 0.0);
+        std::vector<int> wg_free((size_t)nwg, cap), wg_fol((size_t)nwg, 0);
+        std::vector<std::vector<int32_t>> wg_items((size_t)nwg);
+        for (int q = 0; q < nw; ++q) {
+            const int w = idx[(size_t)q];
+            int kk = k[(size_t)w];
+            int best = -1;
+            for (int pass = 0; pass < 2 && best < 0; ++pass) {   // (second pass: the window whole, wherever one slot is free)
+                if (pass == 1) { kk = 1; k[(size_t)w] = 1; }
+                for (int g = 0; g < nwg; ++g)
+                    if (wg_free[(size_t)g] >= kk && wg_fol[(size_t)g] + kk - 1 <= kLdsMaxFollowers && (best < 0 || wg_load[(size_t)g] < wg_load[(size_t)best])) best = g;
+            }
+            wg_load[(size_t)best] += wt[(size_t)w];
+            wg_free[(size_t)best] -= kk;
+            wg_fol[(size_t)best] += kk - 1;
+            wg_items[(size_t)best].push_back(w);
+        }
+        parts_out.assign((size_t)nwg * cap, 0u);
+        for (int g = 0; g < nwg; ++g) {
+            double load[kLdsWaves] = {0};
+            int used[kLdsWaves] = {0};
+            uint32_t next_fol = 0;
+            for (const int32_t w : wg_items[(size_t)g]) {   // (already heaviest first; a split window's parts weigh wt / k each, placed when it comes up)
+                const int kk = k[(size_t)w];
+                uint32_t taken = 0u;                         // wavefronts that hold a part of this window
+                const uint32_t fol0 = next_fol;
+                for (int part = 0; part < kk; ++part) {
+                    int best = -1;
+                    for (int v = 0; v < kLdsWaves; ++v)
+                        if (used[v] < maxw && !((taken >> v) & 1u) && (best < 0 || load[v] < load[best])) best = v;
+                    if (best < 0)   // (cannot happen while kk <= 16 wavefronts have a free slot; keep the stream valid anyway)
+                        for (int v = 0; v < kLdsWaves; ++v) if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
+                    const size_t pos = (size_t)cell_position(g, best, used[best], maxw);
+                    order[pos] = w;
+                    if (kk > 1) parts_out[pos] = (uint32_t)part | ((uint32_t)kk << 8) | ((part == 0 ? fol0 : fol0 + (uint32_t)part - 1u) << 16);
+                    taken |= 1u << best;
+                    load[best] += wt[(size_t)w] / kk;
+                    ++used[best];
+                }
+                if (kk > 1) { next_fol += (uint32_t)kk - 1u; ++nsplit; }
+            }
+        }
+        if (nsplit == 0) parts_out.clear();
+        return;
     }
     // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
     // ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
     const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
-    auto weight = [&](int w) {
-        const double cols = 8.0 * std::max(p->h_bp[(size_t)w], 1);
-        return (int)std::ceil(cols / 32.0 + nranges_d * (1.0 - std::exp(-cols / nranges_d)));
-    };
+    auto weight = [&](int w) { return (int)lds_window_weight(p, w, nranges_d); };
     double total = 0;
     for (int w = 0; w < nw; ++w) total += weight(w);
     std::vector<std::pair<int, int>> blk;   // (weight, window) of the block being dealt
@@ -2012,10 +2108,19 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     const int64_t ncell = (int64_t)nwg * nranges * per_wg;
     uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
     int32_t* d_sorder = nullptr;
-    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); (void)hipFree(d_sorder); return rc; };
+    uint32_t* d_parts_guard = nullptr;   // (set below; freed by bail)
+    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); (void)hipFree(d_sorder); (void)hipFree(d_parts_guard); return rc; };
     std::vector<int32_t> sorder;
-    lds_place_windows(p, nwg, maxw, sorder);
+    std::vector<uint32_t> sparts;
+    int nsplit = 0;
+    lds_place_windows(p, nwg, maxw, sorder, sparts, nsplit);
+    uint32_t* d_parts = nullptr;
     hipError_t e = hipMalloc(&d_cnt, (size_t)(ncell + 1) * sizeof(uint32_t));
+    if (e == hipSuccess && nsplit > 0) {
+        e = hipMalloc(&d_parts, sparts.size() * sizeof(uint32_t));
+        d_parts_guard = d_parts;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_parts, sparts.data(), sparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    }
     if (e == hipSuccess) e = hipMalloc(&d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d_sorder, sorder.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(d_sorder, sorder.data(), sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
@@ -2023,7 +2128,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     const int64_t nthreads = (int64_t)nw * nranges;
     hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, nw, nwg,
-                       nranges, p->Nc, maxw, rows, d_cnt, d_firstq);
+                       nranges, p->Nc, maxw, rows, d_cnt, d_firstq, d_parts);
     // ---- hot / cold: a (workgroup, range) pair is worth a range fill only if enough of the workgroup's columns fall into it
     const int64_t npairs_all = (int64_t)nwg * nranges;
     uint32_t* d_paircols = nullptr;
@@ -2054,6 +2159,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     uint32_t hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
     if (g_spmm_mode == 3 || lds_place_global(p)) hot_min = 1u;   // (the dealt placement has no locality to split on: every pair holds about the same share)
     if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) hot_min = (uint32_t)std::max(1, atoi(env));
+    if (nsplit > 0) hot_min = 1u;   // (the cold remainder is built per whole window)
     std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
     int64_t hot_cols = 0, cold_cols = 0;
     for (int wg = 0; wg < nwg; ++wg) {
@@ -2092,7 +2198,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
     hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
     hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap);
+                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols);
     if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
     e = hipGetLastError();
     // ---- the cold remainder, re-condensed per window for the gather walk
@@ -2140,15 +2246,18 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
     cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols;
-    static const bool verbose = [] { const char* e = getenv("TCGNN_VERBOSE"); return e && atoi(e) > 0; }();
+    cs.d_parts = d_parts; cs.nsplit = nsplit;
+    const char* const verbose_env = getenv("TCGNN_VERBOSE");   // (read per build: builds are rare, and tests switch it on)
+    const bool verbose = verbose_env && atoi(verbose_env) > 0;
     if (verbose)
         fprintf(stderr, "[tcgnn] cell stream %d (%d windows per wavefront, %d-row ranges): %d workgroups x %d ranges, %lld of %lld pairs hot (>= %u columns), "
                         "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
                 slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
-                (long long)ntiles, (long long)cold_tiles, lds_place_global(p) ? "dealt" : "contiguous blocks");
+                (long long)ntiles, (long long)cold_tiles, nsplit ? "longest-first with split hub windows" : (lds_place_global(p) ? "dealt" : "contiguous blocks"));
+    if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
     p->bytes += (size_t)(ncell_hot + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
-                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes;
+                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes + (nsplit ? sparts.size() * sizeof(uint32_t) : 0);
     cs.nranges = nranges;
     return TCGNN_OK;
 }
@@ -2288,7 +2397,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
             SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
-                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate};
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_parts};
             HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
         }
         if (cold) {
@@ -2375,7 +2484,7 @@ static int build_sddmm_stream(tcgnn_plan* p, hipStream_t stream) {
     constexpr int slot = lds_stream_of(2, kLdsMaxW2);
     if (p->lds[slot].nranges <= 0) { const int rc = build_lds_cells(p, stream, slot); if (rc) { sd.built.store(-1); return rc; } }
     const tcgnn_plan::CellStream& cs = p->lds[slot];
-    if (cs.cold_cols > 0) { sd.built.store(-1); return fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM: the plan's cell stream leaves a cold remainder to the gather walk"); }
+    if (cs.cold_cols > 0 || cs.nsplit > 0) { sd.built.store(-1); return fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM: the plan's cell stream leaves a cold remainder to the gather walk or splits hub windows"); }
     const int maxw = kLdsMaxW2, nwg = cs.nwg;
     const int64_t ntiles = cs.tiles, ngroups = (int64_t)cs.npairs * kLdsWaves, ncell = ngroups * maxw;
     uint32_t *d_cnt = nullptr, *d_gsize = nullptr, *d_tile_wr = nullptr, *d_max = nullptr;
@@ -2536,7 +2645,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
-        (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask);
+        (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts);
     }
     if (plan->sd) { (void)hipFree(plan->sd->d_info); (void)hipFree(plan->sd->d_cell_gpos); (void)hipFree(plan->sd->d_gidx); (void)hipFree(plan->sd->d_perm); delete plan->sd; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
