@@ -107,7 +107,7 @@ def sddmm_bytes(n, e, d):
     return 4 * (n + 1) + 8 * e + 4 * n * d
 
 
-def load_profile(kernel, workload):
+def load_profile(kernel, workload, val=None):
     """PMC numbers of (kernel, workload) from the newest profiles/r*/traffic.json - ONLY if that file was collected from the
     sources this process runs (tcgnn_capi.build_id(); tools/collect_profiles.py writes it).  -> (row or None, note).
     A stale or missing profile yields None and says why: the line never quotes counters of another kernel version."""
@@ -126,17 +126,34 @@ def load_profile(kernel, workload):
     if doc.get("build_id") != bid:
         return None, "stale: %s was collected from sources %s, this build is %s (re-run tools/collect_profiles.py)" % (rel, doc.get("build_id"), bid)
     for row in doc.get("rows", []):
-        if row.get("workload") == workload and row.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
-            return row, "%s (build %s)" % (rel, bid)
+        name = row.get("kernel", "")
+        if row.get("workload") != workload or name.split("<")[0] != kernel.split("<")[0]:
+            continue
+        # spmm_kernel / spmm_blocked_kernel exist with and without edge values (last template argument)
+        if val is not None and name.split("<")[0] in ("spmm_kernel", "spmm_blocked_kernel") and name.rstrip(">").split(",")[-1].strip() != ("true" if val else "false"):
+            continue
+        return row, "%s (build %s)" % (rel, bid)
     return None, "%s has no row for %s on %s" % (rel, kernel, workload)
 
 
 MFMA_PEAK = 2.5e15   # fp16 dense, MI355X_MICROARCH.md
 
 
-def profile_fields(kernel, workload, flops, kernel_ms):
-    """traffic + MFMA figures for one kernel on one dataset: PMC-measured where a fresh profile exists, live otherwise."""
-    row, note = load_profile(kernel, workload)
+def profile_fields(kernel, workload, flops, kernel_ms, val=False):
+    """traffic + MFMA figures for one kernel on one dataset: PMC-measured where a fresh profile exists, live otherwise.
+    A leg that runs two kernels ("spmm_lds_kernel + spmm_kernel (cold remainder)") reports the sum of their traffic and the
+    MFMA figures of the first."""
+    names = [k.split("(")[0].strip() for k in kernel.split(" + ")]
+    row, note = load_profile(names[0], workload, val)
+    if row and len(names) > 1:
+        row = dict(row)
+        for extra_name in names[1:]:
+            r2, _ = load_profile(extra_name, workload, val)
+            if r2 is None:
+                row, note = None, note + "; no row for " + extra_name
+                break
+            row["hbm_bytes_per_launch"] = row.get("hbm_bytes_per_launch", 0) + r2.get("hbm_bytes_per_launch", 0)
+            row["mfma_useful_frac"] = None   # (2 E D over one kernel's MFMA count is meaningless when two kernels share the edges)
     out = {"traffic": row.get("hbm_bytes_per_launch") if row else None, "traffic_source": note,
            "mfma_busy": row.get("mfma_busy") if row else None, "mfma_useful_frac": row.get("mfma_useful_frac") if row else None,
            "l2_hit_rate": row.get("l2_hit_rate") if row else None,
@@ -265,7 +282,7 @@ def single_gpu(args):
         if "spmm_val" in ops:
             att_ = torch.randn(1, E_, device=dev, generator=g)
             leg = timed_leg(m_, E_, lambda: TCGNN.forward_AGNN(X_, rp_, col_, att_, bp_, e2c_, e2r_), spmm_bytes(n_, E_, d) + 4 * E_, reps=10)
-            leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
+            leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"], val=True))
             row["spmm_val"] = leg
             del att_
         if "sddmm" in ops:

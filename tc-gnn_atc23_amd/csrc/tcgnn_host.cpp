@@ -11,6 +11,7 @@
 // comes from one monotone walk per row.  No allocation per window, nothing leaked.
 #include <algorithm>
 #include <atomic>
+#include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
