@@ -2159,7 +2159,6 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     uint32_t hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
     if (g_spmm_mode == 3 || lds_place_global(p)) hot_min = 1u;   // (the dealt placement has no locality to split on: every pair holds about the same share)
     if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) hot_min = (uint32_t)std::max(1, atoi(env));
-    if (nsplit > 0) hot_min = 1u;   // (the cold remainder is built per whole window)
     std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
     int64_t hot_cols = 0, cold_cols = 0;
     for (int wg = 0; wg < nwg; ++wg) {
@@ -2232,7 +2231,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, d_kmap, nranges, p->Nc,
-                               maxw, rows, d_cold_ptr, d_ccols, d_cmask);
+                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts);
             e = hipGetLastError();
         }
         cold_bytes = b_ptr + b_c + b_m;

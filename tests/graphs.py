@@ -36,14 +36,15 @@ def powerlaw_graph(n, avg_deg, seed, alpha=1.8, symmetric=True):
     return csr_from_edges(src, dst, n)
 
 
-def hub_rows_graph(n, seed, full_rows=24, half_rows=3, background=30000):
+def hub_rows_graph(n, seed, full_rows=24, half_rows=3, background=30000, bg_cols=None):
     """A few rows that are edges to every (or every second) column over a sparse uniform background, symmetrised: inside a hub's
     window a lane's run of edges within its eight tile columns is up to eight long (the edge-valued kernels fetch four values at a
     time), and the hub columns make every other window hold a dense column block."""
     rng = np.random.default_rng(seed)
     half = np.arange(0, n, 2)
-    src = [np.repeat(np.arange(full_rows), n), rng.integers(0, n, background), np.repeat(np.arange(1000, 1000 + half_rows), len(half))]
-    dst = [np.tile(np.arange(n), full_rows), rng.integers(0, n, background), np.tile(half, half_rows)]
+    m = n if bg_cols is None else bg_cols   # (bg_cols: the background stays inside the first bg_cols nodes - the column ranges beyond hold hub edges only)
+    src = [np.repeat(np.arange(full_rows), n), rng.integers(0, m, background), np.repeat(np.arange(1000, 1000 + half_rows), len(half))]
+    dst = [np.tile(np.arange(n), full_rows), rng.integers(0, m, background), np.tile(half, half_rows)]
     s_, d_ = np.concatenate(src), np.concatenate(dst)
     keep = s_ != d_
     s_, d_ = s_[keep], d_[keep]

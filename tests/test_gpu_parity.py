@@ -439,25 +439,30 @@ def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
         assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
 
 
+@pytest.mark.parametrize("hot", [None, 1800])
 @pytest.mark.parametrize("D", [16, 48, 64, 128])
-def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, capfd, monkeypatch):
+def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, hot, capfd, monkeypatch):
     """Hub rows: a window far heavier than a wavefront's share of its workgroup is split over several wavefronts, each taking
     runs of its tiles in every column range; the partial sums meet in LDS in a fixed order.  Forced LDS-resident walk (mode 3)
     on a graph with a few near-complete rows; against the oracle, the per-window gather walk and itself (deterministic);
     with the fused ReLU and the dense update behind it."""
     import tcgnn_capi as c
-    rp, col = graphs.hub_rows_graph(9000, seed=5, full_rows=20, half_rows=4, background=250000)
+    rp, col = graphs.hub_rows_graph(9000, seed=5, full_rows=20, half_rows=4, background=250000, bg_cols=None if hot is None else 4500)
     n = len(rp) - 1
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     rng = np.random.default_rng(D)
     X = rng.standard_normal((n, D)).astype(np.float32)
     (tX,) = to_dev(dev, X)
     monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    if hot is not None:   # with a cold remainder as well: part 0 of a split window emits the whole window's cold columns
+        monkeypatch.setenv("TCGNN_LDS_HOT_COLS", str(hot))
     T.clear_plan_cache()
     try:
         c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
         Y = T.forward(tX, *meta)[0]
         assert T.last_kernel(*meta).startswith("spmm_lds_kernel")
+        with_cold = "cold remainder" in T.last_kernel(*meta)
+        assert not (hot is None and with_cold)
         again = T.forward(tX, *meta)[0]
         Yr = T.forward_fused(tX, *meta, relu=True)[0]
         W = torch.randn(D, 24, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) if D <= 128 else None
@@ -469,6 +474,8 @@ def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, capfd, 
         T.clear_plan_cache()
     err = capfd.readouterr().err
     assert "windows split over several wavefronts" in err, err[-600:]
+    if hot is not None and D in (16, 64):
+        assert with_cold, err[-600:]   # (the threshold leaves both parts non-empty at these widths' layouts)
     assert torch.equal(Y, again)
     Y64, absY = O.spmm_f64(X, rp, col)
     ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
