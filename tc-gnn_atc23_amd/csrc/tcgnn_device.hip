@@ -90,7 +90,7 @@ struct tcgnn_plan {
         int32_t* d_rlist = nullptr;        // [npairs + 4]
         // cold remainder: columns of the (workgroup, range) pairs too thin for a range fill, re-condensed per window in the gather
         // walks' packed format; run by spmm_kernel, ADDING into what the LDS-resident kernel stored
-        int64_t cold_tiles = 0, hot_cols = 0, cold_cols = 0;
+        int64_t cold_tiles = 0, hot_cols = 0, cold_cols = 0, cold_max = 0;   // cold_max: cold tiles of the longest window
         uint32_t* d_parts = nullptr;       // [slots] split windows: part | parts << 8 | LDS scratch index << 16 (nullptr: no window is split)
         int32_t nsplit = 0;                // windows shared by several wavefronts of their workgroup
         int64_t* d_cold_ptr = nullptr;     // [nw_eff + 1]
@@ -1871,11 +1871,20 @@ static int lds_passes(int dpad, LdsPass (&passes)[2]) {
 }
 // workgroups of one pass: enough to hold every window, spread over every CU a pass can have (with 8 windows per wavefront a
 // 64-column chunk takes two passes, hence half the CUs each)
-static bool lds_place_global(const tcgnn_plan* p) {
-    if (const char* env = getenv("TCGNN_LDS_PLACE")) return !strcmp(env, "global");
+static bool lds_has_hubs(const tcgnn_plan* p) {
     int64_t mx = 0;
     for (int w = 0; w < p->nw_eff; ++w) mx = std::max<int64_t>(mx, p->h_bp[(size_t)w]);
     return mx * p->nw_eff > 4 * std::max<int64_t>(p->tc_blocks, 1);
+}
+// Placements of a cell stream (lds_place_windows): contiguous weight-balanced blocks per workgroup (locality: the hot / cold split,
+// wavefronts of a workgroup busy in the same ranges), the same with hub windows split, or longest-first over the whole graph with
+// hub windows split.  Graphs without hubs take the first; graphs with hubs build the count tables of the other two and keep the
+// one whose estimated time is lower (build_lds_cells).  TCGNN_LDS_PLACE=local|localsplit|global forces one.
+enum { kPlaceLocal = 0, kPlaceLocalSplit = 1, kPlaceGlobal = 2 };
+static int lds_place_forced() {
+    const char* env = getenv("TCGNN_LDS_PLACE");
+    if (!env) return -1;
+    return !strcmp(env, "global") ? kPlaceGlobal : (!strcmp(env, "localsplit") ? kPlaceLocalSplit : kPlaceLocal);
 }
 static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
 // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
@@ -1896,20 +1905,21 @@ static int lds_workgroups_unsplit(const tcgnn_plan* p, int maxw, int extra_slots
 // is the critical path of every range (R-MAT, Reddit shape: the window of the sixteen top hubs holds 3.6 wavefront shares).
 // Such a window is SPLIT: k wavefronts of one workgroup each take every k-th run of its tiles in every range and their partial
 // sums are added through LDS, in a fixed order, at the end of the kernel.  parts[w] = k (1: whole).  Only on graphs that take the
-// dealt placement (lds_place_global); TCGNN_LDS_SPLIT=0 switches it off.
+// graphs with hubs (lds_has_hubs); TCGNN_LDS_SPLIT=0 switches it off.
 static constexpr int kLdsMaxParts = 8, kLdsMaxFollowers = 32;   // (followers of a workgroup: 32 x NT KB of LDS scratch)
-static int lds_split_parts(const tcgnn_plan* p, int maxw, std::vector<uint8_t>* parts) {
+static int lds_split_parts(const tcgnn_plan* p, int maxw, std::vector<uint8_t>* parts, const std::vector<double>* exact = nullptr) {
     static const int enabled = [] { const char* e = getenv("TCGNN_LDS_SPLIT"); return e ? atoi(e) : 1; }();
     const int nw = p->nw_eff;
     if (parts) parts->assign((size_t)nw, 1);
-    if (!enabled || nw <= 0 || !lds_place_global(p)) return 0;
+    if (!enabled || nw <= 0 || !lds_has_hubs(p)) return 0;
     const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
+    auto weight = [&](int w) { return exact ? (*exact)[(size_t)w] : lds_window_weight(p, w, nranges_d); };
     double total = 0;
-    for (int w = 0; w < nw; ++w) total += lds_window_weight(p, w, nranges_d);
+    for (int w = 0; w < nw; ++w) total += weight(w);
     const double share = total / ((double)lds_workgroups_unsplit(p, maxw, 0) * kLdsWaves);
     int extra = 0;
     for (int w = 0; w < nw; ++w) {
-        const double wt = lds_window_weight(p, w, nranges_d);
+        const double wt = weight(w);
         if (wt <= 1.5 * share) continue;
         const int k = (int)std::min<double>(kLdsMaxParts, std::ceil(wt / share));
         if (k < 2) continue;
@@ -1982,7 +1992,36 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
 // Window slots of a cell stream (order[cell_position(wg, wave, j)] = window id or -1): the windows, in their own order, are cut into
 // nwg contiguous blocks of about equal weight (blockPartition = condensed columns) and at most 16 x maxw windows; inside a block
 // they go heaviest-first to the least loaded wavefront that still has a free slot.
-static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit) {
+// One workgroup's windows (heaviest first; a split window's parts weigh wt / k each and are placed when it comes up) go to the
+// least loaded wavefront with a free slot, the parts of one window to different wavefronts.  parts_out (if sized) receives
+// part | parts << 8 | scratch index << 16 for the slots of split windows: scratch index of a follower = its own, of part 0 = its first follower's.
+static void lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& items, const std::vector<uint8_t>& k, const std::vector<double>& wt,
+                               std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit) {
+    double load[kLdsWaves] = {0};
+    int used[kLdsWaves] = {0};
+    uint32_t next_fol = 0;
+    for (const int32_t w : items) {
+        const int kk = k.empty() ? 1 : k[(size_t)w];
+        uint32_t taken = 0u;                         // wavefronts that hold a part of this window
+        const uint32_t fol0 = next_fol;
+        for (int part = 0; part < kk; ++part) {
+            int best = -1;
+            for (int v = 0; v < kLdsWaves; ++v)
+                if (used[v] < maxw && !((taken >> v) & 1u) && (best < 0 || load[v] < load[best])) best = v;
+            if (best < 0)   // (cannot happen while kk <= 16 wavefronts have a free slot; keep the stream valid anyway)
+                for (int v = 0; v < kLdsWaves; ++v) if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
+            const size_t pos = (size_t)cell_position(g, best, used[best], maxw);
+            order[pos] = w;
+            if (kk > 1) parts_out[pos] = (uint32_t)part | ((uint32_t)kk << 8) | ((part == 0 ? fol0 : fol0 + (uint32_t)part - 1u) << 16);
+            taken |= 1u << best;
+            load[best] += wt[(size_t)w] / kk;
+            ++used[best];
+        }
+        if (kk > 1) { next_fol += (uint32_t)kk - 1u; ++nsplit; }
+    }
+}
+static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit,
+                              const std::vector<double>& exact, int mode) {
     const int nw = p->nw_eff, cap = kLdsWaves * maxw;
     order.assign((size_t)nwg * cap, -1);
     parts_out.clear();
@@ -1991,10 +2030,11 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
     // its workgroup and leaves the rest idle, so the workgroup runs several times longer than the mean (R-MAT, Reddit shape: 1.20 ms
     // against 0.85 ms).  When the heaviest window is far above the mean the windows are instead dealt heaviest first, boustrophedon-wise
     // over workgroups and wavefronts - every workgroup gets one hub and a share of the light windows.  TCGNN_LDS_PLACE=global|local forces it.
-    if (lds_place_global(p)) {
+    if (mode == kPlaceGlobal) {
         std::vector<uint8_t> k;
-        const int extra = lds_split_parts(p, maxw, &k);
-        if (extra == 0) {
+        const int extra = lds_split_parts(p, maxw, &k, &exact);
+        const char* const place_env = getenv("TCGNN_LDS_PLACE_DEAL");   // A/B aid: the r01 boustrophedon deal when no window is split
+        if (extra == 0 && place_env && atoi(place_env) > 0) {
             std::vector<int32_t> idx((size_t)nw);
             std::iota(idx.begin(), idx.end(), 0);
             std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return p->h_bp[(size_t)x] > p->h_bp[(size_t)y]; });
@@ -2008,9 +2048,7 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
         // With split windows: longest-processing-time placement.  Windows (a split one with all its parts) go heaviest first to the
         // least loaded workgroup that has the slots; inside a workgroup the items (whole windows and parts) go heaviest first to
         // the least loaded wavefront with a free slot, the parts of one window to different wavefronts.
-        const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
-        std::vector<double> wt((size_t)nw);
-        for (int w = 0; w < nw; ++w) wt[(size_t)w] = lds_window_weight(p, w, nranges_d);
+        const std::vector<double>& wt = exact;
         std::vector<int32_t> idx((size_t)nw);
         std::iota(idx.begin(), idx.end(), 0);
         std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
@@ -2031,67 +2069,44 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
             wg_fol[(size_t)best] += kk - 1;
             wg_items[(size_t)best].push_back(w);
         }
-        parts_out.assign((size_t)nwg * cap, 0u);
-        for (int g = 0; g < nwg; ++g) {
-            double load[kLdsWaves] = {0};
-            int used[kLdsWaves] = {0};
-            uint32_t next_fol = 0;
-            for (const int32_t w : wg_items[(size_t)g]) {   // (already heaviest first; a split window's parts weigh wt / k each, placed when it comes up)
-                const int kk = k[(size_t)w];
-                uint32_t taken = 0u;                         // wavefronts that hold a part of this window
-                const uint32_t fol0 = next_fol;
-                for (int part = 0; part < kk; ++part) {
-                    int best = -1;
-                    for (int v = 0; v < kLdsWaves; ++v)
-                        if (used[v] < maxw && !((taken >> v) & 1u) && (best < 0 || load[v] < load[best])) best = v;
-                    if (best < 0)   // (cannot happen while kk <= 16 wavefronts have a free slot; keep the stream valid anyway)
-                        for (int v = 0; v < kLdsWaves; ++v) if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
-                    const size_t pos = (size_t)cell_position(g, best, used[best], maxw);
-                    order[pos] = w;
-                    if (kk > 1) parts_out[pos] = (uint32_t)part | ((uint32_t)kk << 8) | ((part == 0 ? fol0 : fol0 + (uint32_t)part - 1u) << 16);
-                    taken |= 1u << best;
-                    load[best] += wt[(size_t)w] / kk;
-                    ++used[best];
-                }
-                if (kk > 1) { next_fol += (uint32_t)kk - 1u; ++nsplit; }
-            }
-        }
+        if (extra > 0) parts_out.assign((size_t)nwg * cap, 0u); else k.clear();
+        for (int g = 0; g < nwg; ++g) lds_deal_workgroup(g, maxw, wg_items[(size_t)g], k, wt, order, parts_out, nsplit);
         if (nsplit == 0) parts_out.clear();
         return;
     }
     // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
     // ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
-    const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
-    auto weight = [&](int w) { return (int)lds_window_weight(p, w, nranges_d); };
+    const std::vector<double>& wt = exact;
     double total = 0;
-    for (int w = 0; w < nw; ++w) total += weight(w);
-    std::vector<std::pair<int, int>> blk;   // (weight, window) of the block being dealt
+    for (int w = 0; w < nw; ++w) total += wt[(size_t)w];
+    std::vector<uint8_t> k;
+    const int extra = mode == kPlaceLocalSplit ? lds_split_parts(p, maxw, &k, &exact) : 0;
+    if (extra > 0) parts_out.assign((size_t)nwg * cap, 0u); else k.clear();
+    std::vector<int64_t> slots_after((size_t)nw + 1, 0);   // slots the windows after w need
+    for (int w = nw - 1; w >= 0; --w) slots_after[(size_t)w] = slots_after[(size_t)w + 1] + (k.empty() ? 1 : k[(size_t)w]);
+    std::vector<int32_t> blk;   // windows of the block being dealt
     double acc = 0;
-    int wg = 0;
+    int wg = 0, blk_slots = 0, blk_fol = 0;
     auto deal = [&]() {
-        std::stable_sort(blk.begin(), blk.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
-        int64_t load[kLdsWaves] = {0};
-        int used[kLdsWaves] = {0};
-        for (const auto& it : blk) {
-            int best = -1;
-            for (int v = 0; v < kLdsWaves; ++v)
-                if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
-            order[(size_t)cell_position(wg, best, used[best], maxw)] = it.second;
-            load[best] += it.first;
-            ++used[best];
-        }
-        blk.clear();
+        std::stable_sort(blk.begin(), blk.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
+        lds_deal_workgroup(wg, maxw, blk, k, wt, order, parts_out, nsplit);
+        blk.clear(); blk_slots = 0; blk_fol = 0;
     };
     for (int w = 0; w < nw; ++w) {
-        const int wt = weight(w);
-        blk.emplace_back(wt, w);
-        acc += wt;
-        const int left = nw - (w + 1), wgs_left = nwg - (wg + 1);
-        const bool full = (int)blk.size() == cap;
+        int kk = k.empty() ? 1 : k[(size_t)w];
+        const int wgs_left0 = nwg - (wg + 1);
+        if (kk > 1 && blk_fol + kk - 1 > kLdsMaxFollowers) { k[(size_t)w] = 1; kk = 1; }            // (scratch of the workgroup is full: this one stays whole)
+        if (blk_slots + kk > cap) { if (wgs_left0 > 0) { deal(); ++wg; } else { if (kk > 1) k[(size_t)w] = 1; kk = 1; } }
+        blk.push_back(w);
+        blk_slots += kk; blk_fol += kk - 1;
+        acc += wt[(size_t)w];
+        const int wgs_left = nwg - (wg + 1);
+        const bool full = blk_slots == cap;
         const bool heavy_enough = acc >= total * (double)(wg + 1) / nwg;
-        if (wgs_left > 0 && (full || (heavy_enough && (int64_t)left <= (int64_t)wgs_left * cap))) { deal(); ++wg; }
+        if (wgs_left > 0 && (full || (heavy_enough && slots_after[(size_t)w + 1] <= (int64_t)wgs_left * cap))) { deal(); ++wg; }
     }
     if (!blk.empty()) deal();
+    if (nsplit == 0) parts_out.clear();
 }
 
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
@@ -2110,31 +2125,124 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     int32_t* d_sorder = nullptr;
     uint32_t* d_parts_guard = nullptr;   // (set below; freed by bail)
     auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); (void)hipFree(d_sorder); (void)hipFree(d_parts_guard); return rc; };
-    std::vector<int32_t> sorder;
-    std::vector<uint32_t> sparts;
-    int nsplit = 0;
-    lds_place_windows(p, nwg, maxw, sorder, sparts, nsplit);
-    uint32_t* d_parts = nullptr;
-    hipError_t e = hipMalloc(&d_cnt, (size_t)(ncell + 1) * sizeof(uint32_t));
-    if (e == hipSuccess && nsplit > 0) {
-        e = hipMalloc(&d_parts, sparts.size() * sizeof(uint32_t));
-        d_parts_guard = d_parts;
-        if (e == hipSuccess) e = hipMemcpyAsync(d_parts, sparts.data(), sparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    // exact weight of every window in THIS stream: the tiles it will cost (at least one, so empty windows still take a slot's worth)
+    std::vector<double> exact((size_t)p->nw_eff, 1.0);
+    {
+        uint32_t* d_wt = nullptr;
+        std::vector<uint32_t> h_wt((size_t)p->nw_eff, 0u);
+        hipError_t e0 = hipMalloc(&d_wt, h_wt.size() * sizeof(uint32_t));
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(d_wt, 0, h_wt.size() * sizeof(uint32_t), stream);
+        if (e0 == hipSuccess) {
+            const int64_t nth = (int64_t)p->nw_eff * nranges;
+            hipLaunchKernelGGL(window_tiles_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, p->nw_eff, nranges, p->Nc, rows, d_wt);
+            e0 = hipGetLastError();
+        }
+        if (e0 == hipSuccess) e0 = hipMemcpyAsync(h_wt.data(), d_wt, h_wt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e0 == hipSuccess) e0 = hipStreamSynchronize(stream);
+        (void)hipFree(d_wt);
+        if (e0 != hipSuccess) return fail(e0 == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "window weights: %s", hipGetErrorString(e0));
+        for (size_t w = 0; w < h_wt.size(); ++w) exact[w] = std::max<double>(1.0, h_wt[w]);
     }
-    if (e == hipSuccess) e = hipMalloc(&d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_sorder, sorder.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_sorder, sorder.data(), sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
-    const int64_t nthreads = (int64_t)nw * nranges;
-    hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, nw, nwg,
-                       nranges, p->Nc, maxw, rows, d_cnt, d_firstq, d_parts);
-    // ---- hot / cold: a (workgroup, range) pair is worth a range fill only if enough of the workgroup's columns fall into it
+    // ---- candidate placements: window slots, columns per cell, columns and busiest-wavefront tiles per (workgroup, range) pair,
+    //      and from those an estimate of the kernel time (+ the cold remainder's); the cheapest is built
     const int64_t npairs_all = (int64_t)nwg * nranges;
+    struct Cand {
+        int mode = kPlaceLocal, nsplit = 0;
+        uint32_t hot_min = 1u;
+        double est_us = 0;
+        std::vector<int32_t> sorder;
+        std::vector<uint32_t> sparts, paircols;
+        uint32_t *d_cellcols = nullptr, *d_firstq = nullptr, *d_parts = nullptr;
+        int32_t* d_sorder = nullptr;
+        void release() { (void)hipFree(d_cellcols); (void)hipFree(d_firstq); (void)hipFree(d_parts); (void)hipFree(d_sorder); d_cellcols = d_firstq = d_parts = nullptr; d_sorder = nullptr; }
+    };
+    const char* const verbose_env0 = getenv("TCGNN_VERBOSE");
+    const bool verbose0 = verbose_env0 && atoi(verbose_env0) > 0;
+    auto prepare = [&](int mode, Cand& c) -> hipError_t {
+        c.mode = mode;
+        lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, mode);
+        // threshold: a range step costs a workgroup ~1.7 us (8-window layout, two passes over 256 CUs: ~13 ns of chip time) or
+        // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
+        // (mode 3: tests, timing) keeps every pair that holds a column, and so does the graph-wide placement (no locality to split
+        // on: every pair holds about the same share); TCGNN_LDS_HOT_COLS overrides.
+        c.hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
+        if (g_spmm_mode == 3 || mode == kPlaceGlobal) c.hot_min = 1u;
+        if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) c.hot_min = (uint32_t)std::max(1, atoi(env));
+        uint32_t *d_pc = nullptr, *d_pm = nullptr;
+        hipError_t e = hipMalloc(&c.d_cellcols, (size_t)(ncell + 1) * sizeof(uint32_t));
+        if (e == hipSuccess && c.nsplit > 0) {
+            e = hipMalloc(&c.d_parts, c.sparts.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpyAsync(c.d_parts, c.sparts.data(), c.sparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+        }
+        if (e == hipSuccess) e = hipMalloc(&c.d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c.d_sorder, c.sorder.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_pc, (size_t)npairs_all * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_pm, (size_t)npairs_all * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(c.d_sorder, c.sorder.data(), c.sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c.d_cellcols, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
+        std::vector<uint32_t> pairmax((size_t)npairs_all);
+        c.paircols.resize((size_t)npairs_all);
+        if (e == hipSuccess) {
+            const int64_t nthreads = (int64_t)nw * nranges;
+            hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, c.d_sorder, p->d_cols, nw, nwg,
+                               nranges, p->Nc, maxw, rows, c.d_cellcols, c.d_firstq, c.d_parts);
+            hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, c.d_cellcols, npairs_all, per_wg, maxw, d_pc, d_pm);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(c.paircols.data(), d_pc, c.paircols.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(pairmax.data(), d_pm, pairmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_pc); (void)hipFree(d_pm);
+        if (e != hipSuccess) return e;
+        // every range ends at a barrier: a workgroup's time is the sum over its hot ranges of a fixed part and its busiest
+        // wavefront's tiles (constants of lds_estimate_us); the kernel lasts as long as its slowest workgroup, times the rounds
+        // beyond one workgroup per CU; the cold remainder's columns go through a gather walk at ~20 ps each.
+        const double rounds = std::max(1.0, std::ceil((double)nwg * (maxw == kLdsMaxW2 ? 2 : 1) / std::max(p->num_cus, 1)));
+        auto estimate = [&](uint32_t hot_min) {
+            double worst = 0, cold = 0;
+            for (int wg = 0; wg < nwg; ++wg) {
+                double t = 0;
+                for (int r = 0; r < nranges; ++r) {
+                    const size_t k = (size_t)wg * nranges + r;
+                    if (c.paircols[k] >= hot_min) t += 0.80 + 0.135 * pairmax[k]; else cold += c.paircols[k];
+                }
+                worst = std::max(worst, t);
+            }
+            return worst * rounds + cold * 20e-6;
+        };
+        c.est_us = estimate(c.hot_min);
+        if (verbose0 && mode != kPlaceGlobal)
+            for (uint32_t h : {1u, 125u, 250u, 500u, 1000u, 2000u}) fprintf(stderr, "[tcgnn]   placement %d, hot threshold %u: estimated %.0f us\n", mode, h, estimate(h));
+        return hipSuccess;
+    };
+    Cand best;
+    {
+        const int forced = lds_place_forced();
+        const bool hubs = lds_has_hubs(p);
+        hipError_t e0 = prepare(forced >= 0 ? forced : (hubs ? kPlaceGlobal : kPlaceLocal), best);
+        if (e0 == hipSuccess && forced < 0 && hubs) {
+            Cand other;
+            e0 = prepare(kPlaceLocalSplit, other);
+            if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: estimated %.0f us longest-first over the graph, %.0f us contiguous blocks (+ cold remainder)\n", slot, best.est_us, other.est_us);
+            if (e0 == hipSuccess && other.est_us < best.est_us) std::swap(best, other);
+            other.release();
+        }
+        if (e0 != hipSuccess) { best.release(); return fail(e0 == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e0)); }
+    }
+    std::vector<int32_t>& sorder = best.sorder;
+    std::vector<uint32_t>& sparts = best.sparts;
+    const int nsplit = best.nsplit;
+    const uint32_t hot_min = best.hot_min;
+    const std::vector<uint32_t>& paircols = best.paircols;
+    uint32_t* d_parts = best.d_parts;
+    d_parts_guard = d_parts;
+    d_firstq = best.d_firstq;
+    d_sorder = best.d_sorder;
+    uint32_t* d_cellcols = best.d_cellcols;   // (the dense table of step one holds columns per cell)
+    hipError_t e = hipSuccess;
+    // ---- hot / cold: a (workgroup, range) pair is worth a range fill only if enough of the workgroup's columns fall into it
     uint32_t* d_paircols = nullptr;
     int32_t *d_kmap = nullptr, *d_rbase = nullptr, *d_rlist = nullptr;
-    uint32_t* d_cellcols = d_cnt;   // (the dense table of step one holds columns per cell)
-    d_cnt = nullptr;
     uint32_t* d_coldcols = nullptr;
     int64_t* d_cold_ptr = nullptr;
     int32_t* d_ccols = nullptr;
@@ -2144,21 +2252,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask);
         return bail(rc);
     };
-    e = hipMalloc(&d_paircols, (size_t)npairs_all * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_kmap, (size_t)npairs_all * sizeof(int32_t));
+    e = hipMalloc(&d_kmap, (size_t)npairs_all * sizeof(int32_t));
     if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
-    hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, d_cellcols, npairs_all, per_wg, d_paircols);
-    std::vector<uint32_t> paircols((size_t)npairs_all);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(paircols.data(), d_paircols, paircols.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return bail2(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
-    // threshold: a range step costs a workgroup ~1.7 us (8-window layout, two passes over 256 CUs: ~13 ns of chip time) or
-    // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
-    // (mode 3: tests, timing) keeps every pair that holds a column; TCGNN_LDS_HOT_COLS overrides.
-    uint32_t hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
-    if (g_spmm_mode == 3 || lds_place_global(p)) hot_min = 1u;   // (the dealt placement has no locality to split on: every pair holds about the same share)
-    if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) hot_min = (uint32_t)std::max(1, atoi(env));
     std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
     int64_t hot_cols = 0, cold_cols = 0;
     for (int wg = 0; wg < nwg; ++wg) {
@@ -2201,7 +2296,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
     e = hipGetLastError();
     // ---- the cold remainder, re-condensed per window for the gather walk
-    int64_t cold_tiles = 0;
+    int64_t cold_tiles = 0, cold_max = 0;
     size_t cold_bytes = 0;
     if (e == hipSuccess && cold_cols > 0) {
         const int nwe = p->nw_eff;
@@ -2215,7 +2310,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         if (e == hipSuccess) e = hipMemcpyAsync(coldc.data(), d_coldcols, coldc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         std::vector<int64_t> cptr((size_t)nwe + 1, 0);
-        for (int w = 0; w < nwe; ++w) cptr[(size_t)w + 1] = cptr[(size_t)w] + (coldc[(size_t)w] + 31) / 32;
+        for (int w = 0; w < nwe; ++w) { cptr[(size_t)w + 1] = cptr[(size_t)w] + (coldc[(size_t)w] + 31) / 32; cold_max = std::max<int64_t>(cold_max, (coldc[(size_t)w] + 31) / 32); }
         cold_tiles = cptr[(size_t)nwe];
         const size_t b_ptr = cptr.size() * sizeof(int64_t), b_c = (size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols * 4, b_m = (size_t)std::max<int64_t>(cold_tiles, 1) * kWinRows * 4;
         if (e == hipSuccess) e = hipMalloc(&d_cold_ptr, b_ptr);
@@ -2244,7 +2339,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
-    cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols;
+    cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols; cs.cold_max = cold_max;
     cs.d_parts = d_parts; cs.nsplit = nsplit;
     const char* const verbose_env = getenv("TCGNN_VERBOSE");   // (read per build: builds are rare, and tests switch it on)
     const bool verbose = verbose_env && atoi(verbose_env) > 0;
@@ -2252,7 +2347,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         fprintf(stderr, "[tcgnn] cell stream %d (%d windows per wavefront, %d-row ranges): %d workgroups x %d ranges, %lld of %lld pairs hot (>= %u columns), "
                         "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
                 slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
-                (long long)ntiles, (long long)cold_tiles, nsplit ? "longest-first with split hub windows" : (lds_place_global(p) ? "dealt" : "contiguous blocks"));
+                (long long)ntiles, (long long)cold_tiles, best.mode == kPlaceGlobal ? "longest-first over the graph" : "contiguous blocks");
     if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
     p->bytes += (size_t)(ncell_hot + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
@@ -2405,7 +2500,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             SpmmArgs a{cold->d_cold_ptr, plan->d_order, cold->d_cold_cols, cold->d_cold_mask, reinterpret_cast<const int32_t*>(cold->d_cold_mask), x16_rows, nullptr, hdr, d_Y, plan->N, D, pitch_r, 0, plan->E,
                        plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1};
             static const int cold_w4 = [] { const char* e = getenv("TCGNN_COLD_W4"); return e ? atoi(e) : 48; }();   // tiles per window from which 4 wavefronts share it (SBM Reddit shape, 25 cold tiles per window: 169 us with one wavefront, 202 with four)
-            const int waves = cold->cold_tiles >= (int64_t)cold_w4 * plan->nw_eff ? 4 : 1;
+            // (and a window with hundreds of cold tiles - a hub - is 0.25 us per tile of serial work for one wavefront)
+            const int waves = (cold->cold_tiles >= (int64_t)cold_w4 * plan->nw_eff || cold->cold_max >= 512) ? 4 : 1;
             const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
             if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(false, waves, 8, a, plan->nw_eff, nfull, stream)); }
             if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(false, waves, rem, a, plan->nw_eff, 1, stream)); }

@@ -172,7 +172,7 @@ def rmat_csr(num_nodes, nnz_target, seed=0, device="cpu", abcd=(0.57, 0.19, 0.19
     return _symmetric_csr(n, nnz_target, draw, g, dev, rounds=14)
 
 
-def sbm_csr(num_nodes, nnz_target, seed=0, device="cpu", blocks=50, p_in=0.9, shuffle=False):
+def sbm_csr(num_nodes, nnz_target, seed=0, device="cpu", blocks=50, p_in=0.9, shuffle=False, hubs=0, p_hub=0.0):
     """Seeded stochastic-block-model graph - the "community" variant SURVEY.md 8d asks for next to the uniform one because
     condensing depends on locality: `blocks` equal communities of consecutive ids; an edge stays inside its first endpoint's
     community with probability p_in, else its second endpoint is uniform.  Same post-processing as synthetic_csr.
@@ -191,13 +191,23 @@ def sbm_csr(num_nodes, nnz_target, seed=0, device="cpu", blocks=50, p_in=0.9, sh
         b_in = blk0 + (torch.rand(m, generator=g, device=dev, dtype=torch.float64) * width).long().clamp_(max=size - 1)
         b_in = torch.minimum(b_in, blk0 + width - 1)
         b = torch.where(inside, b_in, torch.randint(0, n, (m,), generator=g, device=dev))
+        if hubs > 0 and p_hub > 0:   # communities AND hubs: a fraction p_hub of the edges starts at one of `hubs` nodes spread over the graph and ends anywhere
+            to_hub = torch.rand(m, generator=g, device=dev) < p_hub
+            hub_id = torch.randint(0, hubs, (m,), generator=g, device=dev) * (n // hubs) + 7
+            a = torch.where(to_hub, hub_id.clamp_(max=n - 1), a)
+            b = torch.where(to_hub, torch.randint(0, n, (m,), generator=g, device=dev), b)
         if perm is not None:
             a, b = perm[a], perm[b]
         return a, b
     return _symmetric_csr(n, nnz_target, draw, g, dev, rounds=10)
 
 
-GENERATORS = {"uniform": synthetic_csr, "rmat": rmat_csr, "sbm": sbm_csr}
+def sbm_hubs_csr(num_nodes, nnz_target, seed=0, device="cpu"):
+    """The 50-community graph with 64 hubs that hold 8 % of the edge endpoints (communities and a power-law tail at once)."""
+    return sbm_csr(num_nodes, nnz_target, seed=seed, device=device, hubs=64, p_hub=0.08)
+
+
+GENERATORS = {"uniform": synthetic_csr, "rmat": rmat_csr, "sbm": sbm_csr, "sbm_hubs": sbm_hubs_csr}
 
 
 def synthetic_shape(name, seed=0, device="cpu", scale=1.0, generator="uniform"):
