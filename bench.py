@@ -373,7 +373,7 @@ def single_gpu(args):
     if not args.no_extra and args.scale == 1.0:
         TCGNN.clear_plan_cache()
         every = ("spmm", "spmm_val", "sddmm", "agnn")
-        for shape, gen, d, ops in ((args.shape, "sbm", D, every), (args.shape, "rmat", D, every),
+        for shape, gen, d, ops in ((args.shape, "sbm", D, every), (args.shape, "rmat", D, every), (args.shape, "sbm_hubs", D, every),
                                    ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
                                    ("ogbn-products", "sbm", 128, every),
                                    ("ogbn-products", "rmat", 128, every)):

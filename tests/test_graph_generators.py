@@ -47,6 +47,15 @@ def test_sbm_keeps_nine_edges_in_ten_inside_the_community_and_condenses_better()
     assert sh["condensed_tiles"] > 0.95 * u["condensed_tiles"]      # the same communities under random labels: invisible
 
 
+def test_sbm_with_hubs_keeps_its_communities_and_grows_a_tail():
+    rp, col = G.sbm_hubs_csr(N, NNZ, seed=1)
+    n, deg, rows, c, _, _ = _facts(rp, col)
+    size = (N + 49) // 50
+    assert float(((rows // size) == (c // size)).float().mean()) > 0.7    # 8 % of the endpoints moved to the hubs, the rest as sbm_csr
+    plain = (G.sbm_csr(N, NNZ, seed=1)[0][1:] - G.sbm_csr(N, NNZ, seed=1)[0][:-1]).max()
+    assert int(deg.max()) > 8 * int(plain)                                 # 64 hubs hold a twelfth of the edges
+
+
 def test_rmat_is_heavy_tailed_and_follows_its_quadrant_weights():
     rp, col = G.rmat_csr(N, NNZ, seed=2)
     n, deg, rows, c, _, _ = _facts(rp, col)
