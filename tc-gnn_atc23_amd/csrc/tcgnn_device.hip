@@ -61,6 +61,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_raw;
 
 struct tcgnn_plan {
     int32_t N = 0, nw = 0, nw_eff = 0;   // N: rows of A (= rows of Y)
+    double near_frac = 0;                // share of the condensed columns within num_cols / 16 rows of their window (locality_kernel)
     int32_t Nc = 0;                      // columns of A = rows of X (== N unless row-sharded)
     int32_t row_off = 0;                 // X row holding A's row 0 (row-sharded SDDMM)
     int64_t E = 0, tc_blocks = 0, total_wb = 0, max_wb = 0;   // max_wb: wide blocks of the longest window
@@ -208,6 +209,28 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
 // ------------------------------------------------------------------------------------------
 // pack: legacy (nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow) -> tile stream
 // ------------------------------------------------------------------------------------------
+// Locality of the numbering: how many condensed columns lie within `reach` rows of their own window.  A uniform random graph gives
+// 2 reach / num_cols (1/8 at reach = num_cols / 16), a graph whose communities are numbered consecutively nearly all of them.
+// Decides between the per-window walk in XCD-contiguous order (co-resident workgroups share their gathered rows in L2) and the
+// range-blocked walk (which picks its windows strided over the whole graph).
+__global__ __launch_bounds__(256) void locality_kernel(const int64_t* __restrict__ wb_ptr, const int32_t* __restrict__ cols, int32_t nw, int32_t Nc,
+                                                       int32_t row_off, int32_t reach, unsigned long long* __restrict__ out) {
+    const int w = blockIdx.x;
+    if (w >= nw) return;
+    const int64_t tb = wb_ptr[w] * kWbCols, n = (wb_ptr[w + 1] - wb_ptr[w]) * kWbCols;
+    const int64_t centre = (int64_t)row_off + (int64_t)w * kWinRows + kWinRows / 2;
+    unsigned near = 0, all = 0;
+    for (int64_t q = threadIdx.x; q < n; q += blockDim.x) {
+        const int32_t c = cols[tb + q];
+        if (c >= Nc) continue;
+        ++all;
+        const int64_t d = (int64_t)c - centre;
+        near += (d < 0 ? -d : d) <= reach;
+    }
+    for (int o = 32; o > 0; o >>= 1) { near += __shfl_down(near, o); all += __shfl_down(all, o); }
+    if ((threadIdx.x & 63) == 0 && all) { atomicAdd(&out[0], (unsigned long long)near); atomicAdd(&out[1], (unsigned long long)all); }
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ col,
                                                    const int32_t* __restrict__ e2c,
@@ -1791,6 +1814,7 @@ static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std:
 // degrees) then holds its wavefront far beyond the others (measured on a Reddit-sized graph with a 93 k-degree hub:
 // 2.48 ms against 1.60 ms for the per-window walk, which spreads a window over 4 wavefronts).  Automatic mode only takes
 // them when the longest window is within 8x the mean.
+static bool has_locality(const tcgnn_plan* plan) { return plan->near_frac > 0.5; }
 static bool windows_balanced(const tcgnn_plan* plan) {
     return plan->nw_eff > 0 && plan->max_wb * (int64_t)plan->nw_eff <= 8 * std::max<int64_t>(plan->total_wb, 1);
 }
@@ -2514,7 +2538,13 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const bool blocked = !d_W && plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
+    // (a numbering with locality keeps the per-window walk: in XCD-contiguous order its co-resident workgroups share their gathered
+    //  rows in L2 - 50-community Reddit shape, edge values: 0.92 ms against 1.18 ms range-blocked; the range-blocked walk is for
+    //  graphs without it, where it wins by 1.4x)
+    const bool blocked = !d_W && plan->nbuckets > 0 && mode != 1 && (mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan) &&
+                                                                                     // (edge values: two windows per wavefront instead of four; at Reddit's 30 MB image the per-window walk
+                                                                                     //  in contiguous order is 6 % faster - 1.70 against 1.79 ms per call - so only images beyond the Infinity Cache's reach)
+                                                                                     (!d_val || x16_bytes > ((size_t)64 << 20))));
     KernelTimer timer(plan, stream, blocked ? "spmm_blocked_kernel" : "spmm_kernel");
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
@@ -2833,6 +2863,22 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build: %s", hipGetErrorString(e)));
     if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
     p->canonical = flags[1] ? 0 : 1;
+    if (nw > 0) {
+        unsigned long long* d_loc = nullptr;
+        unsigned long long h_loc[2] = {0, 0};
+        e = hipMalloc(&d_loc, sizeof h_loc);
+        if (e == hipSuccess) e = hipMemsetAsync(d_loc, 0, sizeof h_loc, stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(locality_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, nw, num_cols, row_offset, std::max(num_cols / 16, kWinRows), d_loc);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_loc, d_loc, sizeof h_loc, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_loc);
+        if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build (locality): %s", hipGetErrorString(e)));
+        p->near_frac = h_loc[1] ? (double)h_loc[0] / (double)h_loc[1] : 0.0;
+        if (const char* v = getenv("TCGNN_VERBOSE")) if (atoi(v) > 0) fprintf(stderr, "[tcgnn] plan: %.0f %% of the condensed columns lie within num_cols / 16 rows of their window\n", 100.0 * p->near_frac);
+    }
     {   // column buckets for the range-blocked SpMM: only when windows are long (>= 2 tiles per bucket on
         // average) and numerous enough to fill the chip with one wavefront per 4 windows (below)
         hipDeviceProp_t prop;
@@ -3048,7 +3094,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
-    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes)));
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
     hipError_t e;
     if (blocked) {
         size_t range_bytes = 4 * kRangeTargetBytes;
