@@ -2826,12 +2826,29 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         for (int w = 0; w < nw; ++w) mx = std::max<int64_t>(mx, bp[(size_t)w]);
         static const int order_mode = [] { const char* e = getenv("TCGNN_ORDER"); return e ? atoi(e) : 0; }();   // 0 automatic, 1 heaviest first, 2 XCD-contiguous
         const bool balanced = nw > 0 && mx * nw <= 4 * std::max<int64_t>(p->tc_blocks, 1);
-        if (order_mode == 2 || (order_mode == 0 && balanced && nw >= 64)) {
-            const int q = nw / 8, r = nw % 8;
-            for (int b = 0; b < nw; ++b) {
-                const int xcd = b % 8, idx = b / 8;
-                order[(size_t)b] = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        // A few hubs over an otherwise even graph (communities + hubs): the K windows more than 4x the mean start first, heaviest first
+        // (the round-robin dispatch spreads them over the XCDs), the rest follows in XCD-contiguous order.  A continuous skew
+        // (R-MAT: the weight falls with the id, the rest is not even either) keeps heaviest-first throughout.
+        int K = 0;
+        if (!balanced && nw >= 64) {
+            const int64_t mean_x4 = 4 * std::max<int64_t>(p->tc_blocks, 1) / nw + 1;
+            while (K < nw && bp[(size_t)order[(size_t)K]] > mean_x4) ++K;
+            int64_t rest = 0, rest_max = 0;
+            for (int q = K; q < nw; ++q) { rest += bp[(size_t)order[(size_t)q]]; rest_max = std::max<int64_t>(rest_max, bp[(size_t)order[(size_t)q]]); }
+            if (K > nw / 16 || rest_max * (int64_t)(nw - K) > 3 * std::max<int64_t>(rest, 1)) K = -1;   // not "a few hubs": keep heaviest-first
+        }
+        if (order_mode == 2 || (order_mode == 0 && nw >= 64 && (balanced || K > 0))) {
+            if (K < 0 || order_mode == 2) K = order_mode == 2 ? 0 : K;
+            std::vector<int32_t> rest;                                   // the windows behind the hubs, in their own order
+            {
+                std::vector<char> is_hub((size_t)nw, 0);
+                for (int q = 0; q < K; ++q) is_hub[(size_t)order[(size_t)q]] = 1;
+                for (int w = 0; w < nw; ++w) if (!is_hub[(size_t)w]) rest.push_back(w);
             }
+            int cnt[8] = {0}, start[9] = {0}, seen[8] = {0};
+            for (int b = K; b < nw; ++b) ++cnt[b % 8];                   // positions XCD x gets behind the hubs
+            for (int x = 0; x < 8; ++x) start[x + 1] = start[x] + cnt[x];
+            for (int b = K; b < nw; ++b) { const int x = b % 8; order[(size_t)b] = rest[(size_t)(start[x] + seen[x]++)]; }
         }
     }
     p->waves = (nw > 0 && p->total_wb >= (int64_t)6 * nw) ? 4 : 1;
