@@ -439,6 +439,41 @@ def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
         assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
 
 
+def test_locality_statistic_of_the_numbering(dev, T, capfd, monkeypatch):
+    """The plan-time statistic behind the choice between the per-window walk in contiguous order and the range-blocked walk
+    (DESIGN.md 4.6): share of the condensed columns within num_cols / 16 rows of their window - 2/16 for a uniform graph, nearly
+    all for consecutively numbered communities; the results of the walks agree either way."""
+    import re
+    import tcgnn_graph as G
+    import tcgnn_capi as c
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    seen = {}
+    for name, (rp, col) in (("uniform", G.synthetic_csr(40000, 2400000, seed=2, device=dev)), ("sbm", G.sbm_csr(40000, 2400000, seed=2, device=dev, blocks=40))):
+        n, E = rp.numel() - 1, col.numel()
+        bp = torch.zeros((n + 15) // 16, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+        T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+        meta = (rp, col, bp, e2c, e2r)
+        T.clear_plan_cache()
+        capfd.readouterr()
+        X = torch.randn(n, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        att = torch.randn(1, E, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        out = {}
+        try:
+            for mode in (0, 1, 2):
+                c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+                out[mode] = (T.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0], T.forward_ef(X, *meta)[0])
+        finally:
+            c.lib.tcgnn_set_spmm_mode(0)
+        m = re.search(r"plan: (\d+) % of the condensed columns", capfd.readouterr().err)
+        assert m, "no locality line"
+        seen[name] = int(m.group(1))
+        scale = float(out[1][0].abs().max()) + 1.0
+        for mode in (0, 2):
+            assert float((out[mode][0] - out[1][0]).abs().max()) <= 1e-4 * scale
+            assert torch.equal(out[mode][1], out[1][1])          # SDDMM: the same products whatever the walk
+    assert 8 <= seen["uniform"] <= 20 and seen["sbm"] >= 75, seen
+
+
 @pytest.mark.parametrize("hot", [None, 1800])
 @pytest.mark.parametrize("D", [16, 48, 64, 128])
 def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, hot, capfd, monkeypatch):
