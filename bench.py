@@ -299,11 +299,13 @@ def single_gpu(args):
             row["agnn_fused_fwd"] = leg
             row["agnn_fused_bwd"] = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_backward(Xs_, rp_, col_, w_, ef_, efm_, bp_, e2c_, e2r_), pb, reps=10)
             del ef_, efm_, Xs_
-        if "agnn_epoch" in ops:
+        if "agnn_epoch" in ops or "gcn_epoch" in ops:
             _, _, in_dim_, classes_ = G.SHAPES[shape]
             feats_ = torch.randn(n_, in_dim_, device=dev, generator=g); labels_ = torch.ones(n_, dtype=torch.long, device=dev)
-            r_ = H.time_training("agnn", m_, feats_, labels_, in_dim_, d, classes_, 2, max(3, args.epochs // 2), seed=args.seed)
-            row["agnn_ms_per_epoch"] = round(r_["train_ms"], 3)
+            for model_ in ("gcn", "agnn"):
+                if model_ + "_epoch" in ops:
+                    r_ = H.time_training(model_, m_, feats_, labels_, in_dim_, d, classes_, 2, max(3, args.epochs // 2), seed=args.seed)
+                    row[model_ + "_ms_per_epoch"] = round(r_["train_ms"], 3)
             del feats_, labels_
         del X_, rp_, col_, bp_, e2c_, e2r_, m_
         TCGNN.clear_plan_cache()
@@ -373,7 +375,8 @@ def single_gpu(args):
     if not args.no_extra and args.scale == 1.0:
         TCGNN.clear_plan_cache()
         every = ("spmm", "spmm_val", "sddmm", "agnn")
-        for shape, gen, d, ops in ((args.shape, "sbm", D, every), (args.shape, "rmat", D, every), (args.shape, "sbm_hubs", D, every),
+        for shape, gen, d, ops in ((args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")),
+                                   (args.shape, "sbm_hubs", D, every),
                                    ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
                                    ("ogbn-products", "sbm", 128, every),
                                    ("ogbn-products", "rmat", 128, every)):

@@ -2019,7 +2019,7 @@ static bool lds_chosen(const tcgnn_plan* p, int dpad) {
 // One workgroup's windows (heaviest first; a split window's parts weigh wt / k each and are placed when it comes up) go to the
 // least loaded wavefront with a free slot, the parts of one window to different wavefronts.  parts_out (if sized) receives
 // part | parts << 8 | scratch index << 16 for the slots of split windows: scratch index of a follower = its own, of part 0 = its first follower's.
-static void lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& items, const std::vector<uint8_t>& k, const std::vector<double>& wt,
+static bool lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& items, const std::vector<uint8_t>& k, const std::vector<double>& wt,
                                std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit) {
     double load[kLdsWaves] = {0};
     int used[kLdsWaves] = {0};
@@ -2032,8 +2032,9 @@ static void lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& item
             int best = -1;
             for (int v = 0; v < kLdsWaves; ++v)
                 if (used[v] < maxw && !((taken >> v) & 1u) && (best < 0 || load[v] < load[best])) best = v;
-            if (best < 0)   // (cannot happen while kk <= 16 wavefronts have a free slot; keep the stream valid anyway)
+            if (best < 0)   // (every free slot sits on a wavefront that already holds a part of this window)
                 for (int v = 0; v < kLdsWaves; ++v) if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
+            if (best < 0) return false;   // more items than slots: the caller's accounting is off - it falls back to a placement without parts
             const size_t pos = (size_t)cell_position(g, best, used[best], maxw);
             order[pos] = w;
             if (kk > 1) parts_out[pos] = (uint32_t)part | ((uint32_t)kk << 8) | ((part == 0 ? fol0 : fol0 + (uint32_t)part - 1u) << 16);
@@ -2043,8 +2044,9 @@ static void lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& item
         }
         if (kk > 1) { next_fol += (uint32_t)kk - 1u; ++nsplit; }
     }
+    return true;
 }
-static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit,
+static bool lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit,
                               const std::vector<double>& exact, int mode) {
     const int nw = p->nw_eff, cap = kLdsWaves * maxw;
     order.assign((size_t)nwg * cap, -1);
@@ -2067,7 +2069,7 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
                 const int wg = (row & 1) ? nwg - 1 - c : c, j = row / kLdsWaves, wv = row % kLdsWaves;
                 order[(size_t)cell_position(wg, (j & 1) ? kLdsWaves - 1 - wv : wv, j, maxw)] = idx[(size_t)q];
             }
-            return;
+            return true;
         }
         // With split windows: longest-processing-time placement.  Windows (a split one with all its parts) go heaviest first to the
         // least loaded workgroup that has the slots; inside a workgroup the items (whole windows and parts) go heaviest first to
@@ -2088,15 +2090,17 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
                 for (int g = 0; g < nwg; ++g)
                     if (wg_free[(size_t)g] >= kk && wg_fol[(size_t)g] + kk - 1 <= kLdsMaxFollowers && (best < 0 || wg_load[(size_t)g] < wg_load[(size_t)best])) best = g;
             }
+            if (best < 0) return false;
             wg_load[(size_t)best] += wt[(size_t)w];
             wg_free[(size_t)best] -= kk;
             wg_fol[(size_t)best] += kk - 1;
             wg_items[(size_t)best].push_back(w);
         }
         if (extra > 0) parts_out.assign((size_t)nwg * cap, 0u); else k.clear();
-        for (int g = 0; g < nwg; ++g) lds_deal_workgroup(g, maxw, wg_items[(size_t)g], k, wt, order, parts_out, nsplit);
+        for (int g = 0; g < nwg; ++g)
+            if (!lds_deal_workgroup(g, maxw, wg_items[(size_t)g], k, wt, order, parts_out, nsplit)) return false;
         if (nsplit == 0) parts_out.clear();
-        return;
+        return true;
     }
     // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
     // ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
@@ -2105,22 +2109,38 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
     for (int w = 0; w < nw; ++w) total += wt[(size_t)w];
     std::vector<uint8_t> k;
     const int extra = mode == kPlaceLocalSplit ? lds_split_parts(p, maxw, &k, &exact) : 0;
-    if (extra > 0) parts_out.assign((size_t)nwg * cap, 0u); else k.clear();
-    std::vector<int64_t> slots_after((size_t)nw + 1, 0);   // slots the windows after w need
+    if (extra > 0) {
+        // the stream has nwg * cap slots (lds_workgroups counted the parts with the modelled weights; the exact ones may ask for
+        // more): take parts back, from the most divided windows first, until everything fits
+        int64_t slots = 0;
+        for (int w = 0; w < nw; ++w) slots += k[(size_t)w];
+        for (int level = kLdsMaxParts; slots > (int64_t)nwg * cap && level > 1; --level)
+            for (int w = 0; w < nw && slots > (int64_t)nwg * cap; ++w)
+                if (k[(size_t)w] == level) { --k[(size_t)w]; --slots; }
+        parts_out.assign((size_t)nwg * cap, 0u);
+    } else k.clear();
+    std::vector<int64_t> slots_after((size_t)nw + 1, 0);   // slots window w and the windows after it need (an upper bound: parts may still be taken back)
     for (int w = nw - 1; w >= 0; --w) slots_after[(size_t)w] = slots_after[(size_t)w + 1] + (k.empty() ? 1 : k[(size_t)w]);
     std::vector<int32_t> blk;   // windows of the block being dealt
     double acc = 0;
     int wg = 0, blk_slots = 0, blk_fol = 0;
+    bool ok = true;
     auto deal = [&]() {
         std::stable_sort(blk.begin(), blk.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
-        lds_deal_workgroup(wg, maxw, blk, k, wt, order, parts_out, nsplit);
+        ok = lds_deal_workgroup(wg, maxw, blk, k, wt, order, parts_out, nsplit) && ok;
         blk.clear(); blk_slots = 0; blk_fol = 0;
     };
-    for (int w = 0; w < nw; ++w) {
+    // invariant: the slots still needed fit into the free slots of this block plus the workgroups left
+    for (int w = 0; w < nw && ok; ++w) {
         int kk = k.empty() ? 1 : k[(size_t)w];
         const int wgs_left0 = nwg - (wg + 1);
         if (kk > 1 && blk_fol + kk - 1 > kLdsMaxFollowers) { k[(size_t)w] = 1; kk = 1; }            // (scratch of the workgroup is full: this one stays whole)
-        if (blk_slots + kk > cap) { if (wgs_left0 > 0) { deal(); ++wg; } else { if (kk > 1) k[(size_t)w] = 1; kk = 1; } }
+        if (blk_slots + kk > cap) {
+            // closing the block leaves its free slots unused: only if what is left still fits into the workgroups behind it
+            if (wgs_left0 > 0 && slots_after[(size_t)w] <= (int64_t)wgs_left0 * cap) { deal(); ++wg; }
+            else { if (kk > 1) k[(size_t)w] = 1; kk = 1; }
+            if (blk_slots + kk > cap) { ok = false; break; }
+        }
         blk.push_back(w);
         blk_slots += kk; blk_fol += kk - 1;
         acc += wt[(size_t)w];
@@ -2129,8 +2149,9 @@ static void lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
         const bool heavy_enough = acc >= total * (double)(wg + 1) / nwg;
         if (wgs_left > 0 && (full || (heavy_enough && slots_after[(size_t)w + 1] <= (int64_t)wgs_left * cap))) { deal(); ++wg; }
     }
-    if (!blk.empty()) deal();
+    if (ok && !blk.empty()) deal();
     if (nsplit == 0) parts_out.clear();
+    return ok;
 }
 
 static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
@@ -2184,13 +2205,16 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     const bool verbose0 = verbose_env0 && atoi(verbose_env0) > 0;
     auto prepare = [&](int mode, Cand& c) -> hipError_t {
         c.mode = mode;
-        lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, mode);
+        if (!lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, mode)) {   // (a placement with parts that ran out of slots)
+            c.mode = kPlaceLocal;
+            if (!lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, kPlaceLocal)) return hipErrorInvalidValue;
+        }
         // threshold: a range step costs a workgroup ~1.7 us (8-window layout, two passes over 256 CUs: ~13 ns of chip time) or
         // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
         // (mode 3: tests, timing) keeps every pair that holds a column, and so does the graph-wide placement (no locality to split
         // on: every pair holds about the same share); TCGNN_LDS_HOT_COLS overrides.
         c.hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
-        if (g_spmm_mode == 3 || mode == kPlaceGlobal) c.hot_min = 1u;
+        if (g_spmm_mode == 3 || c.mode == kPlaceGlobal) c.hot_min = 1u;
         if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) c.hot_min = (uint32_t)std::max(1, atoi(env));
         uint32_t *d_pc = nullptr, *d_pm = nullptr;
         hipError_t e = hipMalloc(&c.d_cellcols, (size_t)(ncell + 1) * sizeof(uint32_t));
@@ -2235,8 +2259,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
             return worst * rounds + cold * 20e-6;
         };
         c.est_us = estimate(c.hot_min);
-        if (verbose0 && mode != kPlaceGlobal)
-            for (uint32_t h : {1u, 125u, 250u, 500u, 1000u, 2000u}) fprintf(stderr, "[tcgnn]   placement %d, hot threshold %u: estimated %.0f us\n", mode, h, estimate(h));
+        if (verbose0 && c.mode != kPlaceGlobal)
+            for (uint32_t h : {1u, 125u, 250u, 500u, 1000u, 2000u}) fprintf(stderr, "[tcgnn]   placement %d, hot threshold %u: estimated %.0f us\n", c.mode, h, estimate(h));
         return hipSuccess;
     };
     Cand best;
@@ -2845,10 +2869,20 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
                 for (int q = 0; q < K; ++q) is_hub[(size_t)order[(size_t)q]] = 1;
                 for (int w = 0; w < nw; ++w) if (!is_hub[(size_t)w]) rest.push_back(w);
             }
+            // every XCD takes one contiguous eighth: the eighths must weigh about the same (a degree that falls with the id -
+            // R-MAT - would hand XCD 0 the heavy end: ogbn-products shape 3.96 -> 4.54 ms), else heaviest-first stays
+            bool even = true;
+            if (order_mode != 2) {
+                int64_t part[8] = {0}, all = 0;
+                for (size_t q = 0; q < rest.size(); ++q) { part[q * 8 / rest.size()] += bp[(size_t)rest[q]]; all += bp[(size_t)rest[q]]; }
+                for (int x = 0; x < 8; ++x) even = even && part[x] * 8 <= all + all / 8;
+            }
+            if (even) {
             int cnt[8] = {0}, start[9] = {0}, seen[8] = {0};
             for (int b = K; b < nw; ++b) ++cnt[b % 8];                   // positions XCD x gets behind the hubs
             for (int x = 0; x < 8; ++x) start[x + 1] = start[x] + cnt[x];
             for (int b = K; b < nw; ++b) { const int x = b % 8; order[(size_t)b] = rest[(size_t)(start[x] + seen[x]++)]; }
+            }
         }
     }
     p->waves = (nw > 0 && p->total_wb >= (int64_t)6 * nw) ? 4 : 1;

@@ -24,7 +24,7 @@ for x in d["datasets"]:
 print()
 print("headline: %.1f %s, step %.4f ms, kernel %.4f ms (all launches %.4f), frac %.4f, traffic %s" % (
     d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms_mean"], d["roofline"]["kernel_ms_mean_all_launches"], d["roofline"]["frac"], d["roofline"]["traffic"]))
-print("epochs: gcn %.3f ms, agnn %.3f ms; products agnn epoch %s" % (ex.get("gcn_ms_per_epoch", 0), ex.get("agnn_ms_per_epoch", 0),
-      [x.get("agnn_ms_per_epoch") for x in d["datasets"] if x.get("agnn_ms_per_epoch")]))
+print("epochs (headline graph): gcn %.3f ms, agnn %.3f ms; other datasets: %s" % (ex.get("gcn_ms_per_epoch", 0), ex.get("agnn_ms_per_epoch", 0),
+      [(x["workload"], x.get("gcn_ms_per_epoch"), x.get("agnn_ms_per_epoch")) for x in d["datasets"] if x.get("agnn_ms_per_epoch") or x.get("gcn_ms_per_epoch")]))
 print("cpu_baseline: %s %s on %s threads (%s); torch.sparse %s" % (d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"]["cores"],
       d["cpu_baseline"]["kind"], d["cpu_baseline"].get("torch_sparse_csr_mm_gteps")))
