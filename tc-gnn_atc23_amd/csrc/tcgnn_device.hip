@@ -2125,8 +2125,19 @@ static bool lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vecto
     double acc = 0;
     int wg = 0, blk_slots = 0, blk_fol = 0;
     bool ok = true;
+    static const int natural = [] { const char* e = getenv("TCGNN_LDS_DEAL_NATURAL"); return e ? atoi(e) : 1; }();
     auto deal = [&]() {
-        std::stable_sort(blk.begin(), blk.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
+        // Even windows are dealt in their own order (least loaded wavefront first = round-robin): a block that spans two communities
+        // then gives every wavefront its share of both, and in a range of either community all sixteen are busy.  Sorting by
+        // weight first is for blocks with windows far above the others.
+        double mx = 0, sum = 0;
+        for (const int32_t w : blk) { mx = std::max(mx, wt[(size_t)w]); sum += wt[(size_t)w]; }
+        if (!natural) std::stable_sort(blk.begin(), blk.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
+        else if (mx * (double)blk.size() > 1.5 * sum) {   // the windows far above the mean first, heaviest first; the others keep their order
+            const double heavy = 2.0 * sum / (double)blk.size();
+            auto mid = std::stable_partition(blk.begin(), blk.end(), [&](int32_t x) { return wt[(size_t)x] > heavy; });
+            std::stable_sort(blk.begin(), mid, [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
+        }
         ok = lds_deal_workgroup(wg, maxw, blk, k, wt, order, parts_out, nsplit) && ok;
         blk.clear(); blk_slots = 0; blk_fol = 0;
     };
