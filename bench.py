@@ -257,11 +257,16 @@ def single_gpu(args):
         return {"gteps": round(E_ / (el / reps) / 1e9, 3), "ms_per_call": round(el * 1e3 / reps, 4), "kernel_ms": round(kmean, 4),
                 "hbm_frac": round(bytes_ / (kmean * 1e-3) / HBM_PEAK, 5), "kernel": TCGNN.last_kernel(*meta_)}
 
-    def dataset_legs(shape, gen, d, ops, seed):
+    def dataset_legs(shape, gen, d, ops, seed, reorder=False):
         """One graph of a named shape from one generator (uniform / rmat / sbm): the kernels named in `ops` at width d, each with
         its HBM fraction by algorithmic bytes, the PMC traffic / MFMA figures of a fresh profile, and the useful MFMA rate."""
         n_, nnz_, _, _ = G.SHAPES[shape]
         rp_, col_ = G.GENERATORS[gen](n_, nnz_, seed=seed, device=dev)
+        reorder_ms = None
+        if reorder:   # the relabelling a loader would apply once (tcgnn_harness --reorder): communities made contiguous
+            torch.cuda.synchronize(); t0_ = time.perf_counter()
+            rp_, col_ = G.permute_csr(rp_, col_, G.community_order(rp_, col_, seed=seed))
+            torch.cuda.synchronize(); reorder_ms = (time.perf_counter() - t0_) * 1e3
         E_ = col_.numel()
         bp_ = torch.zeros((n_ + 15) // 16, dtype=torch.int32, device=dev); e2c_ = torch.zeros(E_, dtype=torch.int32, device=dev); e2r_ = torch.zeros(E_, dtype=torch.int32, device=dev)
         devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); sys.stdout.flush(); os.dup2(devnull, 1)
@@ -273,8 +278,12 @@ def single_gpu(args):
         info_ = TCGNN.plan_info(*m_)
         X_ = torch.randn(n_, d, device=dev, generator=g)
         wl = "%s_%s_d%d" % (shape.replace("ogbn-", ""), gen, d)
-        row = {"dataset": "%s shape, %s generator" % (shape, gen), "workload": wl, "N": n_, "nnz": int(E_), "D": d, "tc_blocks_16x8": info_["tc_blocks"],
+        if reorder:
+            wl += "_reordered"
+        row = {"dataset": "%s shape, %s generator%s" % (shape, gen, ", nodes relabelled by tcgnn_graph.community_order" if reorder else ""), "workload": wl, "N": n_, "nnz": int(E_), "D": d, "tc_blocks_16x8": info_["tc_blocks"],
                "max_degree": int((rp_[1:] - rp_[:-1]).max())}
+        if reorder_ms is not None:
+            row["reorder_ms"] = round(reorder_ms, 1)
         if "spmm" in ops:
             leg = timed_leg(m_, E_, lambda: TCGNN.forward(X_, *m_), spmm_bytes(n_, E_, d), reps=10)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
@@ -376,12 +385,12 @@ def single_gpu(args):
         TCGNN.clear_plan_cache()
         every = ("spmm", "spmm_val", "sddmm", "agnn")
         for shape, gen, d, ops in ((args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")),
-                                   (args.shape, "sbm_hubs", D, every),
+                                   (args.shape, "sbm_hubs", D, every), (args.shape, "sbm_shuffled", D, every), (args.shape, "sbm_shuffled+reorder", D, every + ("gcn_epoch", "agnn_epoch")),
                                    ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
                                    ("ogbn-products", "sbm", 128, every),
                                    ("ogbn-products", "rmat", 128, every)):
             try:
-                datasets.append(dataset_legs(shape, gen, d, ops, args.seed))
+                datasets.append(dataset_legs(shape, gen.split("+")[0], d, ops, args.seed, reorder=gen.endswith("+reorder")))
             except Exception as exc:   # an extra dataset must never take the headline down
                 datasets.append({"dataset": "%s shape, %s generator" % (shape, gen), "error": str(exc)[:300]})
             torch.cuda.empty_cache()

@@ -41,6 +41,8 @@ def build_parser():
     p.add_argument("--graph_dir", type=str, default="tcgnn-ae-graphs/")
     p.add_argument("--gpu_preprocess", action="store_true", help="run the sparse-graph translation on the GPU")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--generator", type=str, default="uniform", help="generator of a --synthetic shape (tcgnn_graph.GENERATORS): uniform, rmat, sbm, sbm_hubs, sbm_shuffled (the communities of sbm under random node ids)")
+    p.add_argument("--reorder", action="store_true", help="relabel the nodes so that communities are contiguous (tcgnn_graph.community_order) before the sparse-graph translation; features and labels follow (not in the reference)")
     p.add_argument("--hip_graph", action="store_true", help="capture one epoch in a HIP graph after the dry epochs and replay it (not in the reference)")
     return p
 
@@ -80,7 +82,7 @@ class Net(nn.Module):
 def load_graph(args):
     import tcgnn_graph as G
     if args.synthetic:
-        rp, col, dim, classes = G.synthetic_shape(args.synthetic, seed=args.seed, scale=args.scale,
+        rp, col, dim, classes = G.synthetic_shape(args.synthetic, seed=args.seed, scale=args.scale, generator=getattr(args, "generator", "uniform"),
                                                    device="cuda" if torch.cuda.is_available() else "cpu")
         n = rp.numel() - 1
         gen = torch.Generator().manual_seed(args.seed)
@@ -166,6 +168,15 @@ def run(args, quiet=False):
     ds = load_graph(args)
     num_nodes, num_edges = ds.num_nodes, ds.num_edges
     column_index, row_pointers = ds.column_index, ds.row_pointers
+    x_host, y_host = ds.x, ds.y
+    if getattr(args, "reorder", False):
+        import tcgnn_graph as G
+        start = time.perf_counter()
+        order = G.community_order(row_pointers.to(device), column_index.to(device), seed=args.seed)
+        row_pointers, column_index = (t.cpu() for t in G.permute_csr(row_pointers.to(device), column_index.to(device), order))
+        x_host, y_host = x_host[order.cpu()], y_host[order.cpu()]
+        torch.cuda.synchronize()
+        say("Reorder:\t{:.3f} ms".format((time.perf_counter() - start) * 1e3))   # (not "(ms):" - 1_log2csv.py:17 would scrape it as a result)
 
     # metadata allocated exactly as main_tcgnn.py:44-47 does (edge arrays sized by the RAW edge count)
     num_row_windows = (num_nodes + BLK_H - 1) // BLK_H
@@ -185,7 +196,7 @@ def run(args, quiet=False):
     say("Prep. (ms):\t{:.3f}".format(prep_ms))
 
     meta = tuple(t.to(device) for t in (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow))
-    x, y = ds.x.to(device), ds.y.to(device)
+    x, y = x_host.to(device), y_host.to(device)
     result = {"prep_ms": prep_ms, "num_nodes": num_nodes, "nnz": int(column_index.numel()), "num_edges_raw": int(num_edges),
               "edge_arrays_len": int(edgeToColumn.numel()), "num_row_windows": int(blockPartition.numel())}
 

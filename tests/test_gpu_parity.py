@@ -439,6 +439,35 @@ def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
         assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
 
 
+def test_reordered_graph_gives_the_same_results_under_the_new_names(dev, T):
+    """tcgnn_graph.community_order + permute_csr rename the nodes; the operators on the renamed graph are the operators on the
+    original one under the renaming: Y'[k] = Y[order[k]], and every edge keeps its score."""
+    import tcgnn_graph as G
+    n, nnz = 30000, 2400000
+    rp, col = G.sbm_csr(n, nnz, seed=9, device=dev, blocks=30, shuffle=True)
+    order = G.community_order(rp, col, seed=9)
+    rp2, col2 = G.permute_csr(rp, col, order)
+    def meta_of(rp_, col_):
+        E_ = col_.numel()
+        bp = torch.zeros((n + 15) // 16, dtype=torch.int32, device=dev); e2c = torch.zeros(E_, dtype=torch.int32, device=dev); e2r = torch.zeros(E_, dtype=torch.int32, device=dev)
+        T.preprocess_gpu(col_, rp_, n, 16, 8, bp, e2c, e2r)
+        return (rp_, col_, bp, e2c, e2r)
+    m1, m2 = meta_of(rp, col), meta_of(rp2, col2)
+    assert int(m2[2].sum()) < 0.8 * int(m1[2].sum())                           # the renamed graph condenses into fewer TC blocks
+    X = torch.randn(n, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    Y1, Y2 = T.forward(X, *m1)[0], T.forward(X[order], *m2)[0]
+    scale = float(Y1.abs().max()) + 1.0
+    assert float((Y2 - Y1[order]).abs().max()) <= 1e-4 * scale                  # (summation order differs: other tiles)
+    ef1, ef2 = T.forward_ef(X, *m1)[0], T.forward_ef(X[order], *m2)[0]
+    assert abs(float(ef1.double().sum()) - float(ef2.double().sum())) <= 1e-6 * float(ef1.double().abs().sum())
+    k = 4321                                                                     # one row's scores, edge by edge
+    old = int(order[k])
+    newid = torch.empty(n, dtype=torch.long, device=dev); newid[order] = torch.arange(n, device=dev)
+    a = dict(zip(newid[col[rp[old]:rp[old + 1]].long()].tolist(), ef1[rp[old]:rp[old + 1]].tolist()))
+    b = dict(zip(col2[rp2[k]:rp2[k + 1]].long().tolist(), ef2[rp2[k]:rp2[k + 1]].tolist()))
+    assert a.keys() == b.keys() and all(abs(a[c] - b[c]) <= 1e-5 * (1.0 + abs(a[c])) for c in a)
+
+
 def test_locality_statistic_of_the_numbering(dev, T, capfd, monkeypatch):
     """The plan-time statistic behind the choice between the per-window walk in contiguous order and the range-blocked walk
     (DESIGN.md 4.6): share of the condensed columns within num_cols / 16 rows of their window - 2/16 for a uniform graph, nearly

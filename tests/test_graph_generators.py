@@ -56,6 +56,28 @@ def test_sbm_with_hubs_keeps_its_communities_and_grows_a_tail():
     assert int(deg.max()) > 8 * int(plain)                                 # 64 hubs hold a twelfth of the edges
 
 
+def test_community_order_finds_the_communities_a_shuffled_numbering_hides():
+    n, nnz, blocks = 12000, 900000, 12
+    rp, col = G.sbm_csr(n, nnz, seed=5, blocks=blocks, shuffle=True)
+    order = G.community_order(rp, col, seed=5)
+    assert order.shape == (n,) and torch.equal(torch.sort(order)[0], torch.arange(n))          # a permutation
+    assert torch.equal(order, G.community_order(rp, col, seed=5))                                # deterministic
+    rp2, col2 = G.permute_csr(rp, col, order)
+    n2, deg2, rows2, c2, symmetric, canonical = _facts(rp2, col2)
+    assert n2 == n and symmetric and canonical and col2.numel() == col.numel()
+    deg = (rp[1:] - rp[:-1]).long()
+    assert torch.equal(deg2, deg[order])                                                         # the same graph, renamed
+    k = 777                                                                                       # ... and the same neighbours
+    old_nb = col[rp[order[k]]:rp[order[k] + 1]].long()
+    newid = torch.empty(n, dtype=torch.long); newid[order] = torch.arange(n)
+    assert torch.equal(torch.sort(newid[old_nb])[0], col2[rp2[k]:rp2[k + 1]].long())
+    near = lambda rows, c: float(((rows - c).abs() <= n // 16).float().mean())
+    _, _, rows, c, _, _ = _facts(rp, col)
+    assert near(rows, c) < 0.2 and near(rows2, c2) > 0.8                                          # 2/16 for a random numbering
+    plain = G.tile_statistics(*G.sbm_csr(n, nnz, seed=5, blocks=blocks))["condensed_tiles"]
+    assert G.tile_statistics(rp2, col2)["condensed_tiles"] < 1.05 * plain < 0.8 * G.tile_statistics(rp, col)["condensed_tiles"]
+
+
 def test_rmat_is_heavy_tailed_and_follows_its_quadrant_weights():
     rp, col = G.rmat_csr(N, NNZ, seed=2)
     n, deg, rows, c, _, _ = _facts(rp, col)

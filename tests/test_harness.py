@@ -101,3 +101,16 @@ def test_metadata_is_allocated_from_the_raw_edge_count_and_device_sgt_trains_the
     assert r_sag["sag_ms"] > 0
     r_agnn = H.run(H.build_parser().parse_args(base[:-1] + ["agnn"]), quiet=True)
     assert np.isfinite(r_agnn["final_loss"])
+
+
+@pytest.mark.gpu
+def test_reorder_flag_relabels_the_graph_and_leaves_the_scraped_lines_alone():
+    """--reorder (tcgnn_graph.community_order before the sparse-graph translation; features and labels follow): the run prints
+    its own line in a format the reference's scraper ignores, condenses the shuffled community graph into fewer TC blocks, and
+    trains to the same loss as the run on the graph as numbered (same model seed; all-ones labels, permuted features)."""
+    base = ("--synthetic", "reddit", "--generator", "sbm_shuffled", "--scale", "0.05", "--dim", "32", "--hidden", "16", "--classes", "6", "--epochs", "3", "--gpu_preprocess")
+    plain, reordered = _run(*base), _run(*base, "--reorder")
+    assert "Reorder:" in reordered and "Reorder:" not in plain
+    assert len(scrape(reordered)[1]) == len(scrape(plain)[1]) == 1
+    blocks = lambda text: int(re.findall(r"TC_Blocks:\s*(\d+)", text)[0])
+    assert blocks(reordered) < 0.9 * blocks(plain)
