@@ -78,6 +78,17 @@ def test_community_order_finds_the_communities_a_shuffled_numbering_hides():
     assert G.tile_statistics(rp2, col2)["condensed_tiles"] < 1.05 * plain < 0.8 * G.tile_statistics(rp, col)["condensed_tiles"]
 
 
+def test_community_order_is_not_taken_over_by_hubs():
+    """Hubs adjacent to every community would carry one label everywhere (plain label propagation ends with a single label on
+    this graph); they receive labels but do not vote."""
+    n, nnz = 12000, 900000
+    kw = dict(seed=6, blocks=12, hubs=8, p_hub=0.08)
+    rp, col = G.sbm_csr(n, nnz, shuffle=True, **kw)
+    rp2, col2 = G.permute_csr(rp, col, G.community_order(rp, col, seed=6))
+    ordered = G.tile_statistics(*G.sbm_csr(n, nnz, **kw))["condensed_tiles"]
+    assert G.tile_statistics(rp2, col2)["condensed_tiles"] < 1.05 * ordered < 0.85 * G.tile_statistics(rp, col)["condensed_tiles"]
+
+
 def test_rmat_is_heavy_tailed_and_follows_its_quadrant_weights():
     rp, col = G.rmat_csr(N, NNZ, seed=2)
     n, deg, rows, c, _, _ = _facts(rp, col)
