@@ -16,7 +16,17 @@ for k in range(cases):
     n = int(rng.integers(1500, 60000)); deg = float(rng.choice([2, 8, 40, 150, 400])); skew = float(rng.choice([0.0, 0.4, 0.8]))
     nnz = int(min(n * deg, 12_000_000))
     D = int(rng.choice([1, 7, 16, 32, 41, 48, 64, 80, 96, 100, 128, 160, 200]))
-    rp, col = G.synthetic_csr(n, nnz, seed=int(rng.integers(1 << 30)), device=dev, skew=skew)
+    gen = str(rng.choice(["uniform", "uniform", "sbm", "sbm_hubs", "rmat"]))
+    seed_ = int(rng.integers(1 << 30))
+    if gen == "uniform": rp, col = G.synthetic_csr(n, nnz, seed=seed_, device=dev, skew=skew)
+    elif gen == "sbm": rp, col = G.sbm_csr(n, max(nnz, 4 * n), seed=seed_, device=dev, blocks=int(rng.choice([3, 10, 50])), p_in=float(rng.choice([0.7, 0.95])))
+    elif gen == "sbm_hubs": rp, col = G.sbm_csr(n, max(nnz, 4 * n), seed=seed_, device=dev, blocks=int(rng.choice([4, 20])), hubs=int(rng.choice([2, 16, 64])), p_hub=float(rng.choice([0.05, 0.2])))
+    else: rp, col = G.rmat_csr(n, max(nnz, 4 * n), seed=seed_, device=dev)
+    # the placement and the hot / cold threshold of the cell stream, at random (read when the stream is built)
+    place = str(rng.choice(["auto", "auto", "local", "localsplit", "global"])); hot = int(rng.choice([0, 0, 1, 50, 300, 1000, 3000]))
+    os.environ.pop("TCGNN_LDS_PLACE", None); os.environ.pop("TCGNN_LDS_HOT_COLS", None)
+    if place != "auto": os.environ["TCGNN_LDS_PLACE"] = place
+    if hot: os.environ["TCGNN_LDS_HOT_COLS"] = str(hot)
     n = rp.numel() - 1; E = col.numel(); nw = (n + 15) // 16
     bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
     os.dup2(fd, 1); TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r); os.dup2(sv, 1)
@@ -26,6 +36,7 @@ for k in range(cases):
     for mode in (1, 3):
         c.check(c.lib.tcgnn_set_spmm_mode(mode), "mode")
         out[mode] = TCGNN.forward(X, *meta)[0]
+        if mode == 3: lds_kernel = TCGNN.last_kernel(*meta)
         ones = TCGNN.forward(torch.ones(n, D, device=dev), *meta)[0]
         degs = (rp[1:] - rp[:-1]).float()
         assert torch.equal(ones, degs[:, None].expand(-1, D)), ("A @ 1 != degree", mode, n, E, D)
@@ -34,7 +45,8 @@ for k in range(cases):
     err = ((out[1] - out[3]).abs() / scale).max().item()
     worst = max(worst, err)
     maxdeg = int((rp[1:] - rp[:-1]).max())
-    print("case %2d: N=%6d E=%9d D=%3d skew %.1f maxdeg %6d : |lds - plain| / scale = %.2e" % (k, n, E, D, skew, maxdeg, err), flush=True)
+    print("case %2d: %-8s N=%6d E=%9d D=%3d skew %.1f maxdeg %6d place %-10s hot %4d %-48s: |lds - plain| / scale = %.2e" % (
+        k, gen, n, E, D, skew, maxdeg, place, hot, lds_kernel, err), flush=True)
     assert err < 2e-3, "mismatch"
     TCGNN.clear_plan_cache() if hasattr(TCGNN, "clear_plan_cache") else None
     del rp, col, bp, e2c, e2r, X, out; torch.cuda.empty_cache()
