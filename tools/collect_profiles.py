@@ -55,7 +55,7 @@ def stats(cmd, name):
 
 
 def pmc_workload(shape, gen, D):
-    tag = "%s_%s_d%d" % (shape.replace("ogbn-", ""), gen, D)
+    tag = "%s_%s_d%d%s" % (shape.replace("ogbn-", ""), gen.split("+")[0], D, "_reordered" if gen.endswith("+reorder") else "")   # (bench.py's workload names)
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = ""
     for grp in PMC_GROUPS:
@@ -112,7 +112,7 @@ def main():
     rows = []
     work = [("reddit", "uniform", 64)] if QUICK else [("reddit", "uniform", 64), ("ogbn-products", "uniform", 128)]
     if ALLGEN:
-        work += [("reddit", "sbm", 64), ("reddit", "rmat", 64), ("reddit", "sbm_hubs", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]
+        work += [("reddit", "sbm", 64), ("reddit", "rmat", 64), ("reddit", "sbm_hubs", 64), ("reddit", "sbm_shuffled", 64), ("reddit", "sbm_shuffled+reorder", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]
     for shape, gen, D in work:
         rows += pmc_workload(shape, gen, D)
     json.dump({"build_id": bid, "round": TAG, "how": __doc__.split("3. traffic.json:")[1].strip(), "rows": rows},

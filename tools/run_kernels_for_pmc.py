@@ -11,7 +11,9 @@ shape, gen, D = sys.argv[1], sys.argv[2], int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = torch.device("cuda:0")
 n, nnz, _, _ = G.SHAPES[shape]
-rp, col = G.GENERATORS[gen](n, nnz, seed=0, device=dev)
+rp, col = G.GENERATORS[gen.split("+")[0]](n, nnz, seed=0, device=dev)
+if gen.endswith("+reorder"):   # the loader-side relabelling (tcgnn_graph.community_order)
+    rp, col = G.permute_csr(rp, col, G.community_order(rp, col, seed=0))
 E = col.numel(); nw = (n + 15) // 16
 bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
 fd = os.dup(1); os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
