@@ -249,8 +249,8 @@ def community_order(row_pointers, column_index, sweeps=24, seed=0, verbose=False
         key = torch.sort(key)[0]
         uniq, counts = torch.unique_consecutive(key, return_counts=True)
         urow, ulab = uniq // n, uniq % n
-        noise = (ulab * 2654435761 + (s + seed) * 40503) % 1021           # tie-break: a hash of the label, new every sweep
-        score = counts * 1024 + noise
+        noise = (ulab * 2654435761 + (s + seed) * 40503) % 251            # tie-break: a hash of the label, new every sweep
+        score = (counts << 40) + (noise << 32) + ulab                      # (the label itself last: exactly one winner per node, whatever the device's write order)
         best = torch.zeros(n, dtype=torch.int64, device=dev).scatter_reduce(0, urow, score, "amax", include_self=True)
         win = score == best[urow]
         proposal = label.clone()
