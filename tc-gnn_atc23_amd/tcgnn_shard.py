@@ -21,6 +21,8 @@ multi-GPU form below is the one SURVEY.md 8(e) derives from the path itself:
 Operators come from a backend: `HipShardOps` (C ABI, tcgnn_plan_create_sharded) on GPUs, or any
 object with the same three methods - the gloo world_size-2 tests on CPU pass an oracle-backed one.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -133,7 +135,7 @@ class HipShardOps:
             self.c.check(self.c.lib.tcgnn_spmm(self.plan, Xg.data_ptr(), Y.data_ptr(), D, ws, nb, torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_spmm")
         return Y
 
-    def spmm_fp16_exchange(self, x_local, layout, rank, group=None):
+    def spmm_fp16_exchange(self, x_local, layout, rank, group=None, always_collective=False):
         """Y_local = A_local @ X with fp16 on the wire: this rank converts ITS rows to the kernels' scaled fp16 image (global
         max|X| from a one-word all-reduce), the image slices are all-gathered (half the bytes of the fp32 gather, and no rank
         stages the whole gathered matrix again) and the SpMM reads the image directly (tcgnn_spmm_staged)."""
@@ -155,15 +157,16 @@ class HipShardOps:
                 self._wire = {}
             self._wire[key] = buf
         image, body, send, word = buf
+        collective = world > 1 or always_collective   # (a world of one can still run the collectives: bench.py's RCCL rehearsal)
         st = torch.cuda.current_stream(dev).cuda_stream
         x_local = x_local.contiguous()
         with torch.cuda.device(dev):
             word.zero_()
             c.check(c.lib.tcgnn_stage_absmax(x_local.data_ptr(), rows * D, word.data_ptr(), st), "tcgnn_stage_absmax")
-            if world > 1:
+            if collective:
                 dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)   # bit patterns of non-negative floats order like ints
             c.check(c.lib.tcgnn_stage_rows(x_local.data_ptr(), rows, D, word.data_ptr(), send.data_ptr(), st), "tcgnn_stage_rows")
-            if world > 1:
+            if collective:
                 all_gather_rows(body[: world * H].view(-1), send[:H].view(-1), group)
             else:
                 body[:H].copy_(send[:H])
@@ -222,11 +225,15 @@ class RowShard:
     """One rank's share of a graph plus the exchange step."""
 
     def __init__(self, row_pointers=None, column_index=None, rank=None, world_size=None, device=None, group=None,
-                 ops_factory=None, bounds=None, local=None):
+                 ops_factory=None, bounds=None, local=None, always_collective=None):
         """Either the whole CSR (row_pointers, column_index; every rank holds it or builds it the
         same way) or `local=(local_row_pointers, global_column_ids)` + `bounds` when each rank only
         ever materialises its own rows (graphs too large for one host/GPU)."""
         self.group = group
+        # a world of one normally skips the exchange; with this switch it still issues every collective of the N-rank step
+        # (all_gather_into_tensor of X / of the fp16 image slices, the one-word all_reduce(MAX)): how a 1-GPU box rehearses
+        # the RCCL calls of the 8-GPU run (bench.py with TCGNN_BENCH_FORCE_SHARDED=1, tests/test_gpu_sharded.py)
+        self.always_collective = bool(int(os.environ.get("TCGNN_SHARD_ALWAYS_COLLECTIVE", "0"))) if always_collective is None else bool(always_collective)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world_size is None else world_size
         self.device = device if device is not None else torch.device("cpu")
@@ -257,7 +264,7 @@ class RowShard:
             self._gbuf[key] = buf
         send, recv = buf
         send[: self.rows].copy_(x_local)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return send
         all_gather_rows(recv, send, self.group)
         return recv
@@ -278,7 +285,7 @@ class RowShard:
     def spmm(self, x_local, wire="fp32"):
         """wire="fp16": the exchange carries the kernels' fp16 image instead of fp32 X (HipShardOps.spmm_fp16_exchange)."""
         if wire == "fp16" and hasattr(self.ops, "spmm_fp16_exchange"):
-            return self.ops.spmm_fp16_exchange(x_local, self.layout, self.rank, self.group)
+            return self.ops.spmm_fp16_exchange(x_local, self.layout, self.rank, self.group, self.always_collective)
         return self.ops.spmm(self.gather(x_local))
 
     def spmm_val(self, x_local, val_local):
@@ -288,10 +295,10 @@ class RowShard:
         return self.ops.sddmm(self.gather(x_local))
 
 
-def allreduce_gradients(params, group=None):
+def allreduce_gradients(params, group=None, always=False):
     """Weight gradients (KBs) are summed with one flat all-reduce; a ring is fine at this size."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, group=group)
@@ -335,9 +342,10 @@ def sharded_train_step(model, shard, x_local, y_local, optimizer, num_nodes_glob
     logp = model(x_local, shard)
     loss_local = -logp.gather(1, y_local.view(-1, 1)).sum() / float(num_nodes_global)
     loss_local.backward()
-    allreduce_gradients(list(model.parameters()), shard.group)
+    always = bool(getattr(shard, "always_collective", False))
+    allreduce_gradients(list(model.parameters()), shard.group, always)
     optimizer.step()
     loss = loss_local.detach().clone()
-    if dist.is_initialized() and dist.get_world_size(shard.group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(shard.group) > 1 or always):
         dist.all_reduce(loss, group=shard.group)
     return loss

@@ -228,10 +228,12 @@ def test_rows_wider_than_the_descriptor_stride_go_as_column_blocks(dev, T):
             refv = O.spmm_val(Xs, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
             v64, av64 = O.spmm_f64(Xs, rp, col, att)
             assert_parity(Yv[:, sl], refv, v64, av64, "spmm_val D=%d cols %d.." % (D, c0))
-        ef = T.forward_ef(tX[:, :D].contiguous(), *meta)[0].cpu().numpy() if D == 4100 else None
-        if ef is not None:                                    # SDDMM beyond 128 columns uses plain pointers: any width
-            e64, ae64 = O.sddmm_f64(X, rp, col)
-            assert (np.abs(ef - e64) / (ae64 + 1.0)).max() <= 2.0 ** -9
+        # SDDMM beyond 128 columns (sddmm_wide_kernel) forms 64-bit addresses from plain pointers - no descriptor, so no stride
+        # field to overflow: any width (r2 ADVICE asked for D > 8192 on a graph above kSmallMaxTiles: this one)
+        ef = T.forward_ef(tX, *meta)[0].cpu().numpy()
+        assert T.last_kernel(*meta) == "sddmm_wide_kernel"
+        e64, ae64 = O.sddmm_f64(X, rp, col)
+        assert (np.abs(ef - e64) / (ae64 + 1.0)).max() <= 2.0 ** -9
 
 
 def test_device_sgt_with_edge_arrays_longer_than_the_csr(dev, T, capfd):

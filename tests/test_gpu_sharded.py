@@ -207,3 +207,93 @@ def test_shard_whose_feature_matrix_needs_64_bit_addresses():
     bad = {k: v for k, v in err.items() if not v <= 2.0 ** -9}
     assert not bad, (bad, err)
     ops.close()
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """World of ONE under backend "nccl" (= RCCL): every collective of the N-rank step executes - all_gather_into_tensor of the
+    fp32 row blocks, the one-word int32 all_reduce(MAX), all_gather_into_tensor of the fp16 image slices into the strided view,
+    the flat all_reduce of the weight gradients and of the loss - and must leave the results of the collective-free path."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tc-gnn_atc23_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ok, notes = {}, []
+    try:
+        rp, col = graphs.uniform_graph(20000, 48, seed=6)
+        n = len(rp) - 1
+        plain = S.RowShard(rp, col, device=dev, always_collective=False)
+        coll = S.RowShard(rp, col, device=dev, always_collective=True)
+        assert dist.get_backend() == "nccl" and coll.world == 1
+        for D in (64, 41, 16):
+            X = torch.randn(n, D, device=dev, generator=torch.Generator(device=dev).manual_seed(D))
+            for mode in (0, 1, 2):
+                try:
+                    c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+                    a = plain.spmm(X)
+                    ok["D=%d mode %d fp32 all-gather under RCCL" % (D, mode)] = bool(torch.equal(a, coll.spmm(X)))
+                    if mode:   # (the staged image is row-major: gather walks)
+                        ok["D=%d mode %d fp16 image all-gather + int32 all-reduce(MAX) under RCCL" % (D, mode)] = bool(torch.equal(plain.spmm(X, wire="fp16"), coll.spmm(X, wire="fp16")))
+                finally:
+                    c.lib.tcgnn_set_spmm_mode(0)
+            ok["D=%d sddmm" % D] = bool(torch.equal(plain.sddmm(X), coll.sddmm(X)))
+        # one whole training step with the gradient / loss all-reduces issued
+        in_dim, hidden, classes = 20, 16, 5
+        Xf = torch.randn(n, in_dim, device=dev) * 0.1
+        y = torch.randint(0, classes, (n,), device=dev)
+        losses = []
+        for sh in (plain, coll):
+            model = S.ShardedGCN(in_dim, hidden, classes, num_layers=2, dropout=0.0, seed=3).to(dev)
+            opt = torch.optim.SGD(model.parameters(), lr=0.5)
+            losses.append((float(S.sharded_train_step(model, sh, Xf, y, opt, n)), [w.detach().clone() for w in model.weights]))
+        ok["training step: loss"] = losses[0][0] == losses[1][0]
+        ok["training step: weights"] = all(torch.equal(a, b) for a, b in zip(losses[0][1], losses[1][1]))
+        dist.barrier()
+        plain.ops.close(); coll.ops.close()
+    except Exception:
+        import traceback
+        ok["exception"] = False
+        notes.append(traceback.format_exc())
+        raise
+    finally:
+        with open(os.path.join(out_dir, "rccl_rank%d.txt" % rank), "w") as f:
+            f.write(repr(ok) + "\n" + "\n".join(notes))
+        np.save(os.path.join(out_dir, "rccl_rank%d.npy" % rank), np.array([int(v) for v in ok.values()] or [0]))
+        dist.destroy_process_group()
+
+
+def test_rccl_world_of_one_executes_every_collective_of_the_n_gpu_step(tmp_path):
+    assert torch.cuda.is_available()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    flags = np.load(os.path.join(tmp_path, "rccl_rank0.npy"))
+    assert flags.size >= 15 and flags.all(), open(os.path.join(tmp_path, "rccl_rank0.txt")).read()
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_prints_one_json_line_last():
+    """`python bench.py --gpus N` with no launcher (the form the driver uses at N = 1): the sharded path is forced with a
+    world of one, so the self-launch (torch.distributed.run on 127.0.0.1), the RCCL process group and the exchange inside the
+    timed step all execute; the last stdout line is the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TCGNN_BENCH_FORCE_SHARDED="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--scale", "0.05", "--steps", "5", "--warmup", "2", "--epochs", "4"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms_mean"] > 0
+    ex = line["extra"]
+    assert ex["exchange_in_timed_step"] is True
+    assert ex["ms_per_step_with_exchange"] > 0 and ex["ms_per_step_with_fp16_exchange"] is not None
+    assert ex["gcn_ms_per_epoch_sharded"] is not None

@@ -169,3 +169,48 @@ def test_two_rank_sharded_gcn_step_equals_single_process_step(tmp_path):
     for r in range(2):
         flags = np.load(os.path.join(tmp_path, "gcn_rank%d.npy" % r))
         assert flags.all(), open(os.path.join(tmp_path, "gcn_rank%d.txt" % r)).read()
+
+
+def test_bench_self_launch_builds_a_torchrun_command_on_localhost(monkeypatch):
+    """`python bench.py --gpus N` without RANK in the environment starts N ranks itself: the command is
+    torch.distributed.run with one process per GPU, a rendezvous on 127.0.0.1 and bench.py's own arguments."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_a_world_of_one_can_still_issue_the_collectives(tmp_path):
+    """RowShard(always_collective=True): the gather and the gradient / loss all-reduces run even with one rank (how a 1-GPU box
+    rehearses the RCCL calls); the results are those of the collective-free path."""
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        rp, col = graphs.powerlaw_graph(300, 10, seed=2)
+        X = torch.from_numpy(np.random.default_rng(0).standard_normal((300, 8)).astype(np.float32))
+        a = S.RowShard(rp, col, ops_factory=OracleShardOps, always_collective=False)
+        b = S.RowShard(rp, col, ops_factory=OracleShardOps, always_collective=True)
+        assert b.gather(X).shape[0] == b.layout.num_cols and torch.equal(a.spmm(X), b.spmm(X)) and torch.equal(a.sddmm(X), b.sddmm(X))
+    finally:
+        dist.destroy_process_group()
