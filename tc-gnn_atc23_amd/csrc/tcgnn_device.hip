@@ -99,6 +99,11 @@ struct tcgnn_plan {
         uint32_t* d_cold_mask = nullptr;   // [cold_tiles][16]
         uint32_t* d_cell_ptr = nullptr;    // [nwg * nranges * 16 * maxw + 1] tile offset of cell (workgroup, range, wavefront, window slot)
         uint32_t* d_cell_tiles = nullptr;  // [tiles][32] 32 u16 row ids local to the range + 16 mask words
+        // FLAT stream (tcgnn_lds_flat.inc): every cell of a hot pair has exactly flat_tpc tiles at a computed position - no cell
+        // table, no ordinary tiles; what a cell holds beyond 32 flat_tpc columns sits in the cold remainder, which
+        // spmm_cold_planar_kernel adds from the planar image.  0: an ordinary stream.
+        int32_t flat_tpc = 0;
+        uint32_t* d_flat = nullptr;        // [npairs][16 wavefronts][32 * maxw * flat_tpc words] metadata blocks
     };
     CellStream lds[6];   // (kLdsStreams)
     mutable std::atomic<int8_t> lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
@@ -108,7 +113,6 @@ struct tcgnn_plan {
     mutable std::vector<hipEvent_t> ev;
     mutable std::atomic<int> ev_used{0};
     mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
-    struct SdStream* sd = nullptr;   // metadata of the LDS-resident SDDMM (tcgnn_lds_sddmm.inc), built on its first call
     std::vector<int32_t> h_bp;       // blockPartition on the host: window weights for the placement of the LDS-resident walks
     mutable std::atomic<int> lds_extra[2] = {{-1}, {-1}};   // window slots the split hub windows add (4 / 8 windows per wavefront); -1: not computed
 };
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
 }
 
 #include "tcgnn_lds_spmm.inc"
-#include "tcgnn_lds_sddmm.inc"
+#include "tcgnn_lds_flat.inc"
 
 // ------------------------------------------------------------------------------------------
 // SDDMM:  ef[e] = <X16[row e], X16[col e]>
@@ -2207,7 +2211,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         uint32_t hot_min = 1u;
         double est_us = 0;
         std::vector<int32_t> sorder;
-        std::vector<uint32_t> sparts, paircols;
+        std::vector<uint32_t> sparts, paircols, pairover, pairtiles;   // pairover: [2][pairs] columns beyond 32 / 64 per cell
         uint32_t *d_cellcols = nullptr, *d_firstq = nullptr, *d_parts = nullptr;
         int32_t* d_sorder = nullptr;
         void release() { (void)hipFree(d_cellcols); (void)hipFree(d_firstq); (void)hipFree(d_parts); (void)hipFree(d_sorder); d_cellcols = d_firstq = d_parts = nullptr; d_sorder = nullptr; }
@@ -2227,7 +2231,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         c.hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
         if (g_spmm_mode == 3 || c.mode == kPlaceGlobal) c.hot_min = 1u;
         if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) c.hot_min = (uint32_t)std::max(1, atoi(env));
-        uint32_t *d_pc = nullptr, *d_pm = nullptr;
+        uint32_t *d_pc = nullptr, *d_pm = nullptr, *d_po = nullptr, *d_pt = nullptr;
         hipError_t e = hipMalloc(&c.d_cellcols, (size_t)(ncell + 1) * sizeof(uint32_t));
         if (e == hipSuccess && c.nsplit > 0) {
             e = hipMalloc(&c.d_parts, c.sparts.size() * sizeof(uint32_t));
@@ -2237,21 +2241,27 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         if (e == hipSuccess) e = hipMalloc(&c.d_sorder, c.sorder.size() * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc(&d_pc, (size_t)npairs_all * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(&d_pm, (size_t)npairs_all * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_po, (size_t)npairs_all * 2 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_pt, (size_t)npairs_all * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpyAsync(c.d_sorder, c.sorder.data(), c.sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipMemsetAsync(c.d_cellcols, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
         std::vector<uint32_t> pairmax((size_t)npairs_all);
         c.paircols.resize((size_t)npairs_all);
+        c.pairover.resize((size_t)npairs_all * 2);
+        c.pairtiles.resize((size_t)npairs_all);
         if (e == hipSuccess) {
             const int64_t nthreads = (int64_t)nw * nranges;
             hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, c.d_sorder, p->d_cols, nw, nwg,
                                nranges, p->Nc, maxw, rows, c.d_cellcols, c.d_firstq, c.d_parts);
-            hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, c.d_cellcols, npairs_all, per_wg, maxw, d_pc, d_pm);
+            hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, c.d_cellcols, npairs_all, per_wg, maxw, d_pc, d_pm, d_po, d_pt);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(c.paircols.data(), d_pc, c.paircols.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c.pairover.data(), d_po, c.pairover.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c.pairtiles.data(), d_pt, c.pairtiles.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(pairmax.data(), d_pm, pairmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_pc); (void)hipFree(d_pm);
+        (void)hipFree(d_pc); (void)hipFree(d_pm); (void)hipFree(d_po); (void)hipFree(d_pt);
         if (e != hipSuccess) return e;
         // every range ends at a barrier: a workgroup's time is the sum over its hot ranges of a fixed part and its busiest
         // wavefront's tiles (constants of lds_estimate_us); the kernel lasts as long as its slowest workgroup, times the rounds
@@ -2306,8 +2316,9 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     int64_t* d_cold_ptr = nullptr;
     int32_t* d_ccols = nullptr;
     uint32_t* d_cmask = nullptr;
+    uint32_t* d_flat = nullptr;
     auto bail2 = [&](int rc) {
-        (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_rbase); (void)hipFree(d_rlist); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
+        (void)hipFree(d_flat); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_rbase); (void)hipFree(d_rlist); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
         (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask);
         return bail(rc);
     };
@@ -2327,6 +2338,31 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     const int64_t npairs = (int64_t)rlist.size();
     rlist.resize(rlist.size() + 4, 0);
     const int64_t ncell_hot = npairs * per_wg;
+    // ---- flat or ordinary (tcgnn_lds_flat.inc): a flat stream gives every cell of a hot pair exactly tpc tiles and sends what
+    //      a cell holds beyond 32 tpc columns to the cold remainder.  Taken when that costs few columns (the cold remainder of a
+    //      flat stream is added by a latency-bound kernel) and no more tile steps than the ordinary stream's; never with split
+    //      hub windows (their cells are nowhere near uniform).  TCGNN_LDS_FLAT=0 / 1 / 2 forces ordinary / one / two tiles per cell.
+    int flat_tpc = 0;
+    int64_t over_cols = 0;
+    {
+        int64_t classic_tiles = 0, over[2] = {0, 0};
+        for (int64_t k = 0; k < npairs_all; ++k)
+            if (kmap[(size_t)k] >= 0) { classic_tiles += best.pairtiles[(size_t)k]; over[0] += best.pairover[(size_t)k]; over[1] += best.pairover[(size_t)(npairs_all + k)]; }
+        const char* fenv = getenv("TCGNN_LDS_FLAT");
+        const int forced_flat = fenv ? atoi(fenv) : -1;
+        if (nsplit == 0 && npairs > 0 && forced_flat != 0) {
+            for (int tpc = 1; tpc <= 2 && !flat_tpc; ++tpc) {
+                if (maxw * tpc > 16) break;
+                const int64_t flat_tiles = ncell_hot * tpc;
+                const bool few_cold = (double)(cold_cols + over[tpc - 1]) <= 0.04 * (double)std::max<int64_t>(hot_cols + cold_cols, 1);
+                const bool no_more_steps = (double)flat_tiles <= 1.03 * (double)std::max<int64_t>(classic_tiles, 1);
+                if (forced_flat == tpc || (forced_flat < 0 && few_cold && no_more_steps)) { flat_tpc = tpc; over_cols = over[tpc - 1]; }
+            }
+        }
+        if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: %lld tiles ordinary; flat would take %lld (+%lld columns cold) / %lld (+%lld): %s\n", slot, (long long)classic_tiles,
+                              (long long)ncell_hot, (long long)over[0], (long long)(2 * ncell_hot), (long long)over[1], flat_tpc ? (flat_tpc == 1 ? "flat, 1 tile per cell" : "flat, 2 tiles per cell") : "ordinary");
+    }
+    hot_cols -= over_cols; cold_cols += over_cols;
     e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&d_rbase, rbase.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&d_rlist, rlist.size() * sizeof(int32_t));
@@ -2342,7 +2378,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return bail2(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
     uint64_t run = 0;
-    for (size_t k = 0; k < cnt.size(); ++k) { const uint32_t c = cnt[k]; cnt[k] = (uint32_t)run; run += c; }
+    if (flat_tpc) run = (uint64_t)ncell_hot * (uint64_t)flat_tpc;   // (positions are computed: the table is not kept)
+    else for (size_t k = 0; k < cnt.size(); ++k) { const uint32_t c = cnt[k]; cnt[k] = (uint32_t)run; run += c; }
     if (run >= (1ull << 32)) return bail2(fail(TCGNN_ERR_BAD_GRAPH, "LDS-range SpMM: %llu tiles overflow the 32-bit cell table", (unsigned long long)run));
     const int64_t ntiles = (int64_t)run;
     const int64_t nwords = std::max<int64_t>(ntiles, 1) * kCellWords;
@@ -2351,9 +2388,20 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
     hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
     hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols);
+                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols, flat_tpc);
     if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
     e = hipGetLastError();
+    if (e == hipSuccess && flat_tpc) {   // tiles -> per-(pair, wavefront) metadata blocks; the ordinary tiles and the cell table go
+        e = hipMalloc(&d_flat, (size_t)nwords * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(flat_transpose_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, d_flat, npairs * kLdsWaves, maxw * flat_tpc);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_tiles); d_tiles = nullptr;
+        (void)hipFree(d_cnt); d_cnt = nullptr;
+        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "flat cell stream: %s", hipGetErrorString(e)));
+    }
     // ---- the cold remainder, re-condensed per window for the gather walk
     int64_t cold_tiles = 0, cold_max = 0;
     size_t cold_bytes = 0;
@@ -2363,7 +2411,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         e = hipMalloc(&d_coldcols, (size_t)nwe * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(d_coldcols, 0, (size_t)nwe * sizeof(uint32_t), stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_coldcols);
+            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_coldcols,
+                               (uint32_t)(32 * flat_tpc));
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(coldc.data(), d_coldcols, coldc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -2385,7 +2434,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, d_kmap, nranges, p->Nc,
-                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts);
+                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts, d_firstq, (uint32_t)(32 * flat_tpc));
             e = hipGetLastError();
         }
         cold_bytes = b_ptr + b_c + b_m;
@@ -2396,6 +2445,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     tcgnn_plan::CellStream& cs = p->lds[slot];
     cs.d_order = d_sorder;
     cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
+    cs.flat_tpc = flat_tpc; cs.d_flat = d_flat;
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
     cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols; cs.cold_max = cold_max;
@@ -2407,9 +2457,10 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
                         "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
                 slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
                 (long long)ntiles, (long long)cold_tiles, best.mode == kPlaceGlobal ? "longest-first over the graph" : "contiguous blocks");
+    if (verbose && flat_tpc) fprintf(stderr, "[tcgnn]   flat: %d tile(s) per cell, %lld columns beyond the cells' tiles moved to the cold remainder\n", flat_tpc, (long long)over_cols);
     if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
-    p->bytes += (size_t)(ncell_hot + 1) * sizeof(uint32_t) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
+    p->bytes += (flat_tpc ? 0 : (size_t)(ncell_hot + 1) * sizeof(uint32_t)) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
                 (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes + (nsplit ? sparts.size() * sizeof(uint32_t) : 0);
     cs.nranges = nranges;
     return TCGNN_OK;
@@ -2483,13 +2534,16 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     const tcgnn_plan::CellStream* cold = nullptr;
     if (lds) {
         const tcgnn_plan::CellStream& c0 = plan->lds[lds_stream_of(passes[0].nt, passes[0].maxw)];
-        bool any_cold = false, thin = false;
+        bool any_cold = false, thin = false, flat_cold = false;
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& ci = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
-            any_cold = any_cold || ci.cold_tiles > 0;
+            // (a flat stream's remainder is added per pass from the planar image by spmm_cold_planar_kernel: no second image, any
+            //  number of passes - but not under the fused dense update, which needs the whole sum before it multiplies)
+            if (ci.flat_tpc) flat_cold = flat_cold || ci.cold_tiles > 0;
+            else any_cold = any_cold || ci.cold_tiles > 0;
             thin = thin || ci.hot_cols * 2 < ci.hot_cols + ci.cold_cols;
         }
-        if (any_cold && (npass > 1 || d_W)) lds = false;
+        if ((any_cold && (npass > 1 || d_W)) || (flat_cold && d_W)) lds = false;
         else if (thin && mode != 3) { lds = false; if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0; }
         else if (any_cold) cold = &c0;
     }
@@ -2546,9 +2600,25 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                           false, hdr);
             if (rc) return rc;
         }
-        KernelTimer timer(plan, stream, cold ? "spmm_lds_kernel + spmm_kernel (cold remainder)" : "spmm_lds_kernel");
+        const tcgnn_plan::CellStream& cs0 = plan->lds[lds_stream_of(passes[0].nt, passes[0].maxw)];
+        KernelTimer timer(plan, stream, cold ? "spmm_lds_kernel + spmm_kernel (cold remainder)" :
+                                        (cs0.flat_tpc ? (cs0.cold_tiles > 0 ? "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)" : "spmm_lds_flat_kernel") : "spmm_lds_kernel"));
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
+            if (cs.flat_tpc) {
+                const bool has_cold = cs.cold_tiles > 0;
+                SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate};
+                HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
+                if (has_cold && !(g_lds_dbg & 16)) {
+                    const int cd = lds_chunk_dims(passes[i].maxw);
+                    const int col0 = passes[i].chunk0 * cd, ncols = std::min(passes[i].nchunks * cd, dpad - col0);
+                    const ColdPlanarArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, col0, ncols, relu};
+                    hipLaunchKernelGGL(spmm_cold_planar_kernel, dim3((unsigned)((plan->nw_eff + 3) / 4), (unsigned)((ncols + 63) / 64)), dim3(256), 0, stream, ca);
+                    HIP_TRY(hipGetLastError());
+                }
+                continue;
+            }
             SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
                           cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_parts};
             HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
@@ -2602,115 +2672,6 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, 8, a, plan->nw_eff, nfull, stream)); }
     if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, rem, a, plan->nw_eff, 1, stream)); }
-    return TCGNN_OK;
-}
-
-// ---- LDS-resident SDDMM: eligibility, plan-time metadata, launch --------------------------------------------------------------
-// Measured on the Reddit shape at D = 64 (profiles/r02/sddmm_lds_*): pass 1 1.59 ms + pass 2 0.36 ms against 1.66 ms for the gather
-// walk - the compaction of each tile's ~26 real scores out of 512 products goes through the LDS pipeline (59 LDS cycles per
-// tile against 17 for the SpMM), which then is the bound.  Correct and tested, but not the default: TCGNN_SDDMM_LDS=1 or
-// tcgnn_set_spmm_mode(3) select it.
-static int g_sddmm_lds = [] { const char* e = getenv("TCGNN_SDDMM_LDS"); return e ? atoi(e) : 0; }();
-static int g_sd_dbg = [] { const char* e = getenv("TCGNN_SD_DBG"); return e ? atoi(e) : 0; }();
-static int sd_passes(int D) { return (round_up(D, 16) + 31) / 32; }
-// Taken when the SpMM time models pick the LDS-resident kernel for a 64-column matrix on this plan (the same cell stream, the
-// same streaming pattern), the rows are canonical, every offset fits its field, and the width is at most 8 passes.
-static bool sddmm_lds_eligible(const tcgnn_plan* p, int D) {
-    if (!(g_sddmm_lds || g_spmm_mode == 3) || !p || !p->canonical || p->nw_eff <= 0 || p->E < 1 || D < 1 || D > 256) return false;
-    if (p->sd && p->sd->built.load() < 0) return false;
-    if (g_spmm_mode == 1 || g_spmm_mode == 2 || g_spmm_mode == 4) return false;
-    if ((uint64_t)p->E * 4u >= (1ull << 32)) return false;                                       // 32-bit stream positions
-    if ((int64_t)((D + 15) / 16) * ((int64_t)p->Nc + 1) * 32 >= ((int64_t)1 << 32)) return false;   // the range filler's descriptor
-    return g_spmm_mode == 3 || lds_chosen(p, 64);
-}
-static size_t sd_partial_bytes(const tcgnn_plan* p, int D) {
-    return sddmm_lds_eligible(p, D) ? (((size_t)sd_passes(D) * (size_t)p->E * sizeof(float)) + 255) / 256 * 256 : 0;
-}
-
-__global__ void sd_max_window_kernel(const int32_t* __restrict__ rowptr, int32_t N, int32_t nw, uint32_t* out) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nw) return;
-    const int64_t r0 = (int64_t)w * kWinRows, r1 = r0 + kWinRows < N ? r0 + kWinRows : N;
-    atomicMax(out, (uint32_t)(rowptr[r1] - rowptr[r0]));
-}
-
-static int build_sddmm_stream(tcgnn_plan* p, hipStream_t stream) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!p->sd) p->sd = new (std::nothrow) SdStream();
-    if (!p->sd) return fail(TCGNN_ERR_OOM, "sddmm stream: host allocation failed");
-    SdStream& sd = *p->sd;
-    if (sd.built.load() != 0) return sd.built.load() > 0 ? TCGNN_OK : fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM unavailable on this plan");
-    constexpr int slot = lds_stream_of(2, kLdsMaxW2);
-    if (p->lds[slot].nranges <= 0) { const int rc = build_lds_cells(p, stream, slot); if (rc) { sd.built.store(-1); return rc; } }
-    const tcgnn_plan::CellStream& cs = p->lds[slot];
-    if (cs.cold_cols > 0 || cs.nsplit > 0) { sd.built.store(-1); return fail(TCGNN_ERR_UNSUPPORTED, "LDS-resident SDDMM: the plan's cell stream leaves a cold remainder to the gather walk or splits hub windows"); }
-    const int maxw = kLdsMaxW2, nwg = cs.nwg;
-    const int64_t ntiles = cs.tiles, ngroups = (int64_t)cs.npairs * kLdsWaves, ncell = ngroups * maxw;
-    uint32_t *d_cnt = nullptr, *d_gsize = nullptr, *d_tile_wr = nullptr, *d_max = nullptr;
-    int32_t* d_flags = nullptr;
-    auto bail = [&](int rc) {
-        (void)hipFree(d_cnt); (void)hipFree(d_gsize); (void)hipFree(d_tile_wr); (void)hipFree(d_max); (void)hipFree(d_flags);
-        (void)hipFree(sd.d_info); (void)hipFree(sd.d_cell_gpos); (void)hipFree(sd.d_gidx); (void)hipFree(sd.d_perm);
-        sd.d_info = nullptr; sd.d_cell_gpos = nullptr; sd.d_gidx = nullptr; sd.d_perm = nullptr;
-        sd.built.store(-1);   // the gather walk serves this plan from now on
-        return rc;
-    };
-    const size_t nt1 = (size_t)std::max<int64_t>(ntiles, 1);
-    hipError_t e = hipMalloc(&d_cnt, nt1 * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_gsize, (size_t)(ngroups + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_tile_wr, nt1 * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_max, 4);
-    if (e == hipSuccess) e = hipMalloc(&d_flags, 4);
-    if (e == hipSuccess) e = hipMalloc(&sd.d_info, nt1 * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc(&sd.d_cell_gpos, (size_t)(ncell + 1) * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 4, stream);
-    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "sddmm stream: %s", hipGetErrorString(e)));
-    if (ntiles > 0) hipLaunchKernelGGL(sd_tile_count_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, cs.d_cell_tiles, ntiles, d_cnt);
-    hipLaunchKernelGGL(sd_group_size_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, ngroups, maxw, d_gsize);
-    hipLaunchKernelGGL(sd_max_window_kernel, dim3((unsigned)((p->nw_eff + 255) / 256)), dim3(256), 0, stream, p->rowptr, p->N, p->nw_eff, d_max);
-    std::vector<uint32_t> gs((size_t)ngroups + 1);
-    uint32_t max_win = 0;
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(gs.data(), d_gsize, (size_t)ngroups * 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&max_win, d_max, 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "sddmm stream (sizes): %s", hipGetErrorString(e)));
-    uint64_t run = 0;
-    for (int64_t k = 0; k < ngroups; ++k) { const uint32_t c = gs[(size_t)k]; gs[(size_t)k] = (uint32_t)run; run += c; }
-    if (run >= (1ull << 32)) return bail(fail(TCGNN_ERR_UNSUPPORTED, "sddmm stream: %llu index bytes overflow 32 bits", (unsigned long long)run));
-    gs[(size_t)ngroups] = (uint32_t)run;
-    sd.perm32 = max_win > 65535u ? 1 : 0;
-    sd.max_window_edges = max_win;
-    const size_t b_gidx = (size_t)std::max<uint64_t>(run, 16), b_perm = (size_t)std::max<int64_t>(p->E, 1) * (sd.perm32 ? 4 : 2);
-    e = hipMalloc(&sd.d_gidx, b_gidx);
-    if (e == hipSuccess) e = hipMalloc(&sd.d_perm, b_perm);
-    if (e == hipSuccess) e = hipMemsetAsync(sd.d_gidx, 0, b_gidx, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_gsize, gs.data(), (size_t)(ngroups + 1) * 4, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "sddmm stream (%zu + %zu bytes): %s", b_gidx, b_perm, hipGetErrorString(e)));
-    hipLaunchKernelGGL(sd_group_fill_kernel, dim3((unsigned)((ngroups + 1 + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, d_gsize, ngroups, maxw,
-                       (uint32_t)run, sd.d_info, sd.d_cell_gpos);
-    const int nslots = nwg * kLdsWaves * maxw;
-    hipLaunchKernelGGL(sd_window_base_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, cs.d_cell_ptr, d_cnt, cs.d_order, p->rowptr,
-                       nslots, cs.d_rbase, cs.d_rlist, maxw, p->N, sd.d_info, d_tile_wr);
-    if (ntiles > 0) {
-        const int rows = lds_stream_buf_rows(slot) - 8;
-        if (sd.perm32) hipLaunchKernelGGL((sd_tile_fill_kernel<uint32_t>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, cs.d_cell_tiles, sd.d_info, d_tile_wr,
-                                          p->rowptr, p->col, ntiles, rows, p->N, sd.d_gidx, static_cast<uint32_t*>(sd.d_perm), d_flags);
-        else hipLaunchKernelGGL((sd_tile_fill_kernel<uint16_t>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, cs.d_cell_tiles, sd.d_info, d_tile_wr,
-                                p->rowptr, p->col, ntiles, rows, p->N, sd.d_gidx, static_cast<uint16_t*>(sd.d_perm), d_flags);
-    }
-    int32_t flag = 0;
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flags, 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "sddmm stream (fill): %s", hipGetErrorString(e)));
-    if (flag) return bail(fail(TCGNN_ERR_BAD_GRAPH, "sddmm stream: a tile column has no CSR edge (metadata inconsistent with the CSR)"));
-    (void)hipFree(d_cnt); (void)hipFree(d_gsize); (void)hipFree(d_tile_wr); (void)hipFree(d_max); (void)hipFree(d_flags);
-    sd.bytes = nt1 * sizeof(uint4) + (size_t)(ncell + 1) * 4 + b_gidx + b_perm;
-    p->bytes += sd.bytes;
-    sd.built.store(1);
     return TCGNN_OK;
 }
 
@@ -2805,9 +2766,8 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
-        (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts);
+        (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
     }
-    if (plan->sd) { (void)hipFree(plan->sd->d_info); (void)hipFree(plan->sd->d_cell_gpos); (void)hipFree(plan->sd->d_gidx); (void)hipFree(plan->sd->d_perm); delete plan->sd; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -3043,8 +3003,21 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     // (the fused AGNN calls' reduction slots and the partial score streams of the LDS-resident SDDMM ride along)
     // ... and the second (row-major) image of a plan whose LDS-resident walk leaves a cold remainder to the gather walk
     const size_t image = workspace_bytes_for(plan->Nc, D);
-    const bool two_images = plan->nw_eff > 0 && (g_spmm_mode == 3 || (g_spmm_mode == 0 && lds_chosen(plan, round_up(D, 16))));
-    return image + std::max({agnn_partial_bytes(plan), sd_partial_bytes(plan, D), two_images ? image : (size_t)0});
+    // (before the width's streams exist the answer is the conservative one; once built, only an ORDINARY stream with a cold
+    //  remainder stages the second image - a flat stream's remainder reads the planar one)
+    bool two_images = plan->nw_eff > 0 && (g_spmm_mode == 3 || (g_spmm_mode == 0 && lds_chosen(plan, round_up(D, 16))));
+    if (two_images) {
+        LdsPass passes[2];
+        const int np = lds_passes(round_up(D, 16), passes);
+        bool all_built = np > 0, cold_rows = false;
+        for (int i = 0; i < np; ++i) {
+            const tcgnn_plan::CellStream& ci = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
+            all_built = all_built && ci.nranges > 0;
+            cold_rows = cold_rows || (ci.nranges > 0 && !ci.flat_tpc && ci.cold_tiles > 0);
+        }
+        if (all_built && !cold_rows) two_images = false;
+    }
+    return image + std::max({agnn_partial_bytes(plan), two_images ? image : (size_t)0});
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {
@@ -3114,39 +3087,6 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    // ---- LDS-resident column ranges (tcgnn_lds_sddmm.inc) where the time models pick that walk for this plan
-    bool lds = sddmm_lds_eligible(plan, D);
-    if (lds && !(plan->sd && plan->sd->built.load() > 0)) {
-        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) lds = false;   // (built by the next eager call)
-        else if (build_sddmm_stream(const_cast<tcgnn_plan*>(plan), stream) != TCGNN_OK) lds = false;
-    }
-    if (lds) {
-        const size_t image = workspace_bytes_for(plan->Nc, D), need = image + sd_partial_bytes(plan, D);
-        if (!ws || ws_bytes < need) return fail(TCGNN_ERR_WORKSPACE, "tcgnn_sddmm: workspace needs %zu bytes, got %zu", need, ws_bytes);
-        int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, /*planar=*/true);
-        if (rc) return rc;
-        const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(2, kLdsMaxW2)];
-        const SdStream& sd = *plan->sd;
-        float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + image);
-        const int npass = sd_passes(D);
-        SddmmLdsArgs l{cs.d_cell_ptr, sd.d_cell_gpos, cs.d_cell_tiles, sd.d_info, sd.d_gidx, cs.d_order, x16, part, plan->E,
-                       plan->N, plan->Nc, plan->row_off, dpad / 16, plan->Nc + 1, cs.nranges, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist};
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void*)sddmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSdLdsBytes));
-            attr_set = true;
-        }
-        KernelTimer timer(plan, stream, "sddmm_lds_kernel");
-        hipLaunchKernelGGL(sddmm_lds_kernel, dim3((unsigned)cs.nwg, (unsigned)npass), dim3(kLdsWaves * 64), kSdLdsBytes, stream, l);
-        const int seg_cap = (int)std::min<uint32_t>((uint32_t)kSdFinishSeg, std::max<uint32_t>(256u, (sd.max_window_edges + 255u) & ~255u));
-        if (sd.perm32) hipLaunchKernelGGL((sddmm_finish_kernel<uint32_t>), dim3((unsigned)plan->nw_eff), dim3(512), (size_t)seg_cap * sizeof(float), stream, part, npass,
-                                          plan->E, plan->rowptr, static_cast<const uint32_t*>(sd.d_perm), hdr, plan->N, plan->nw_eff, d_ef, g_sd_dbg, seg_cap);
-        else hipLaunchKernelGGL((sddmm_finish_kernel<uint16_t>), dim3((unsigned)plan->nw_eff), dim3(512), (size_t)seg_cap * sizeof(float), stream, part, npass,
-                                plan->E, plan->rowptr, static_cast<const uint16_t*>(sd.d_perm), hdr, plan->N, plan->nw_eff, d_ef, g_sd_dbg, seg_cap);
-        HIP_TRY(hipGetLastError());
-        return TCGNN_OK;
-    }
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};

@@ -402,45 +402,6 @@ def test_lds_resident_range_kernel_matches_oracle_and_plain_walk(dev, T, D, shap
     for mode in (1, 3):
         assert_parity(out[mode], ref, Y64, absY, "spmm mode %d" % mode)
 
-@pytest.mark.parametrize("D", [16, 32, 41, 64, 100, 128, 200])
-@pytest.mark.parametrize("shape", ["dense", "ragged", "very_dense", "empty_window"])
-def test_lds_resident_sddmm_matches_oracle_and_gather_walk(dev, T, D, shape):
-    """The LDS-resident column-range SDDMM (tcgnn_lds_sddmm.inc: ranges of the planar image streamed into LDS, scores compacted
-    through a plan-time index into a window-major stream, second pass to CSR order; the automatic choice on Reddit-like graphs)
-    forced on graphs small enough for the oracle: several ranges, a ragged last window and range, hubs whose wavefront holds
-    more tiles / edges in one range than its pads (the per-tile slow path), half tiles with more than 64 edges (several
-    compaction rounds), a window without edges, 1 .. 7 passes of 32 columns with and without a zero plane at the end."""
-    import tcgnn_capi as c
-    if shape == "dense":
-        rp, col = graphs.uniform_graph(4100, 150, seed=21)
-    elif shape == "ragged":
-        rp, col = graphs.powerlaw_graph(2061, 9.0, seed=22)
-    elif shape == "very_dense":
-        rp, col = graphs.uniform_graph(1500, 700, seed=23)        # ~40 % dense: > 64 edges per half tile, > 512 index bytes per range
-    else:
-        rp, col = graphs.with_empty_window(*graphs.uniform_graph(2000, 60, seed=24), 32, 48)
-    n, nnz = len(rp) - 1, len(col)
-    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
-    rng = np.random.default_rng(D + 5)
-    X = (rng.standard_normal((n, D)) * float(rng.choice([0.02, 1.0, 50.0]))).astype(np.float32)
-    (tX,) = to_dev(dev, X)
-    out = {}
-    try:
-        for mode in (1, 3):
-            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
-            out[mode] = T.forward_ef(tX, *meta)[0]
-            assert T.last_kernel(*meta) == ("sddmm_lds_kernel" if mode == 3 else ("sddmm_kernel" if D <= 128 else "sddmm_wide_kernel")), mode
-        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
-        again = T.forward_ef(tX, *meta)[0]
-    finally:
-        c.lib.tcgnn_set_spmm_mode(0)
-    assert torch.equal(out[3], again)                                        # deterministic
-    ef64, absef = O.sddmm_f64(X, rp, col)
-    ref = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
-    for mode in (1, 3):
-        assert_parity(out[mode].cpu().numpy(), ref, ef64, absef, "sddmm mode %d" % mode, unit_scale=False)
-
-
 def test_reordered_graph_gives_the_same_results_under_the_new_names(dev, T):
     """tcgnn_graph.community_order + permute_csr rename the nodes; the operators on the renamed graph are the operators on the
     original one under the renaming: Y'[k] = Y[order[k]], and every edge keeps its score."""
@@ -526,7 +487,7 @@ def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, hot, ca
     try:
         c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
         Y = T.forward(tX, *meta)[0]
-        assert T.last_kernel(*meta).startswith("spmm_lds_kernel")
+        assert T.last_kernel(*meta).startswith("spmm_lds_")
         with_cold = "cold remainder" in T.last_kernel(*meta)
         assert not (hot is None and with_cold)
         again = T.forward(tX, *meta)[0]
@@ -552,6 +513,63 @@ def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, hot, ca
         ref_w = Y64 @ W.double().cpu().numpy()
         bound = (absY @ np.abs(W.double().cpu().numpy())) * 2.0 ** -9 + 1e-6
         assert (np.abs(Yw.cpu().numpy() - ref_w) <= bound).all()
+
+
+@pytest.mark.parametrize("D", [16, 32, 41, 64, 100, 128, 160])
+@pytest.mark.parametrize("flat", ["1", "2"])
+@pytest.mark.parametrize("shape", ["dense", "denser", "ragged"])
+def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat, shape, monkeypatch, capfd):
+    """r03: the LDS-resident walk over a FLAT cell stream (tcgnn_lds_flat.inc): every cell of a (workgroup, range) pair has exactly
+    1 or 2 tiles at a computed position, the range body is straight-line code, and the columns a cell holds beyond its tiles go
+    to the cold remainder, which spmm_cold_planar_kernel adds from the planar image.  Forced here (mode 3 + TCGNN_LDS_FLAT) on
+    graphs whose cells overflow often (`denser`: ~50 columns per 760-row cell against a cap of 32) and hardly ever, every layout
+    (1-4 planes x 4 windows, 2 planes x 8 windows), against the oracle, the per-window gather walk and the ordinary stream; the
+    fused ReLU / gate and determinism ride along."""
+    import tcgnn_capi as c
+    if shape == "dense":
+        rp, col = graphs.uniform_graph(4100, 150, seed=21)
+    elif shape == "denser":
+        rp, col = graphs.uniform_graph(3000, 400, seed=23)
+    else:
+        rp, col = graphs.powerlaw_graph(2061, 9.0, seed=22)      # N % 16 = 13; hub windows (split parts keep the ordinary stream)
+    n = len(rp) - 1
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 5)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    (tX,) = to_dev(dev, X)
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    out = {}
+    try:
+        for f in (flat, "0"):
+            monkeypatch.setenv("TCGNN_LDS_FLAT", f)
+            T.clear_plan_cache()
+            c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+            Y = T.forward(tX, *meta)[0]
+            out[f] = (Y, T.last_kernel(*meta), T.forward_fused(tX, *meta, relu=True)[0], T.forward_fused(tX, *meta, gate=Y)[0], T.forward(tX, *meta)[0])
+        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+        Y1 = T.forward(tX, *meta)[0]
+        Yg1 = T.forward_fused(tX, *meta, gate=out[flat][0])[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+    err = capfd.readouterr().err
+    Y, kernel, Yr, Yg, again = out[flat]
+    if "windows split over several wavefronts" in err:
+        assert kernel.startswith("spmm_lds_kernel"), kernel          # split hub windows keep the ordinary stream
+    else:
+        assert kernel.startswith("spmm_lds_flat_kernel"), (kernel, err[-800:])
+        assert ("flat, %s tile" % flat) in err or ("flat: %s tile" % flat) in err, err[-800:]
+        if shape == "denser" and flat == "1":
+            assert kernel == "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)", kernel
+    assert out["0"][1].startswith("spmm_lds_kernel")
+    assert torch.equal(Y, again)
+    Y64, absY = O.spmm_f64(X, rp, col)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(Y.cpu().numpy(), ref, Y64, absY, "flat stream")
+    assert_parity(out["0"][0].cpu().numpy(), ref, Y64, absY, "ordinary stream")
+    assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+    assert torch.equal(Yr, torch.relu(Y))
+    assert np.abs(Yg.cpu().numpy() - Yg1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
 
 
 @pytest.mark.parametrize("D", [16, 48, 64, 96, 128])
@@ -1050,7 +1068,7 @@ def test_dense_update_fused_behind_the_aggregation(dev, T, case, dims):
 
 
 @pytest.mark.parametrize("dims", [(64, 41), (32, 48), (41, 64), (48, 16)])
-def test_dense_update_on_the_lds_resident_kernel(dev, T, dims):
+def test_dense_update_on_the_lds_resident_kernel(dev, T, dims, monkeypatch):
     """The same on a graph dense enough for the LDS-resident kernel (forced: mode 3): a 64-column input runs as two 32-column
     passes that ADD their products into a zeroed Y (two addends - bit-reproducible), narrower inputs as one pass that stores."""
     import tcgnn_capi as c
@@ -1063,6 +1081,8 @@ def test_dense_update_on_the_lds_resident_kernel(dev, T, dims):
     meta = (rp, col, bp, e2c, e2r)
     g = torch.Generator(device=dev).manual_seed(din + dout)
     X = torch.randn(n, din, device=dev, generator=g); W = torch.randn(din, dout, device=dev, generator=g) / din ** 0.5
+    monkeypatch.setenv("TCGNN_LDS_FLAT", "0")   # (the ordinary cell stream: a flat one with a cold remainder leaves the fused update to the gather walk)
+    T.clear_plan_cache()
     try:
         c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
         agg = T.forward(X, *meta)[0]
@@ -1115,7 +1135,7 @@ def test_gcn_layer_that_aggregates_first_trains_like_the_reference_order(dev, T)
     gin = L.GINConv(64, 41).to(dev)
     with torch.no_grad():
         y_fused = gin(x, *meta)
-    assert T.last_kernel(*meta) in ("spmm_kernel", "spmm_lds_kernel")
+    assert T.last_kernel(*meta).split(" ")[0] in ("spmm_kernel", "spmm_lds_kernel", "spmm_lds_flat_kernel")
     y_two = gin(x.clone().requires_grad_(True), *meta)
     assert ((y_fused - y_two).abs() / (y_two.abs() + 10.0)).max().item() <= 1e-5
 
