@@ -2211,7 +2211,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         uint32_t hot_min = 1u;
         double est_us = 0;
         std::vector<int32_t> sorder;
-        std::vector<uint32_t> sparts, paircols, pairover, pairtiles;   // pairover: [2][pairs] columns beyond 32 / 64 per cell
+        std::vector<uint32_t> sparts, paircols, pairmax, pairover, pairtiles;   // pairover: [2][pairs] columns beyond 32 / 64 per cell
         uint32_t *d_cellcols = nullptr, *d_firstq = nullptr, *d_parts = nullptr;
         int32_t* d_sorder = nullptr;
         void release() { (void)hipFree(d_cellcols); (void)hipFree(d_firstq); (void)hipFree(d_parts); (void)hipFree(d_sorder); d_cellcols = d_firstq = d_parts = nullptr; d_sorder = nullptr; }
@@ -2245,7 +2245,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         if (e == hipSuccess) e = hipMalloc(&d_pt, (size_t)npairs_all * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpyAsync(c.d_sorder, c.sorder.data(), c.sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipMemsetAsync(c.d_cellcols, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
-        std::vector<uint32_t> pairmax((size_t)npairs_all);
+        std::vector<uint32_t>& pairmax = c.pairmax;
+        pairmax.resize((size_t)npairs_all);
         c.paircols.resize((size_t)npairs_all);
         c.pairover.resize((size_t)npairs_all * 2);
         c.pairtiles.resize((size_t)npairs_all);
@@ -2345,9 +2346,12 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     int flat_tpc = 0;
     int64_t over_cols = 0;
     {
-        int64_t classic_tiles = 0, over[2] = {0, 0};
+        // (what a range lasts is its busiest wavefront's tile steps - every range ends at a barrier: pairmax for the ordinary
+        //  stream, maxw x tpc for a flat one, whose empty window slots are skipped but whose wavefronts all wait for a full one)
+        int64_t classic_tiles = 0, classic_steps = 0, over[2] = {0, 0};
         for (int64_t k = 0; k < npairs_all; ++k)
-            if (kmap[(size_t)k] >= 0) { classic_tiles += best.pairtiles[(size_t)k]; over[0] += best.pairover[(size_t)k]; over[1] += best.pairover[(size_t)(npairs_all + k)]; }
+            if (kmap[(size_t)k] >= 0) { classic_tiles += best.pairtiles[(size_t)k]; classic_steps += best.pairmax[(size_t)k];
+                                        over[0] += best.pairover[(size_t)k]; over[1] += best.pairover[(size_t)(npairs_all + k)]; }
         const char* fenv = getenv("TCGNN_LDS_FLAT");
         const int forced_flat = fenv ? atoi(fenv) : -1;
         if (nsplit == 0 && npairs > 0 && forced_flat != 0) {
@@ -2355,12 +2359,14 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
                 if (maxw * tpc > 16) break;
                 const int64_t flat_tiles = ncell_hot * tpc;
                 const bool few_cold = (double)(cold_cols + over[tpc - 1]) <= 0.04 * (double)std::max<int64_t>(hot_cols + cold_cols, 1);
-                const bool no_more_steps = (double)flat_tiles <= 1.03 * (double)std::max<int64_t>(classic_tiles, 1);
+                (void)flat_tiles;
+                const bool no_more_steps = (double)(npairs * maxw * tpc) <= 1.0 * (double)std::max<int64_t>(classic_steps, 1);
                 if (forced_flat == tpc || (forced_flat < 0 && few_cold && no_more_steps)) { flat_tpc = tpc; over_cols = over[tpc - 1]; }
             }
         }
-        if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: %lld tiles ordinary; flat would take %lld (+%lld columns cold) / %lld (+%lld): %s\n", slot, (long long)classic_tiles,
-                              (long long)ncell_hot, (long long)over[0], (long long)(2 * ncell_hot), (long long)over[1], flat_tpc ? (flat_tpc == 1 ? "flat, 1 tile per cell" : "flat, 2 tiles per cell") : "ordinary");
+        if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: %lld tiles ordinary, %lld steps of the busiest wavefronts; flat would take %lld steps (+%lld columns cold) / %lld (+%lld): %s\n", slot,
+                              (long long)classic_tiles, (long long)classic_steps, (long long)(npairs * maxw), (long long)over[0], (long long)(2 * npairs * maxw), (long long)over[1],
+                              flat_tpc ? (flat_tpc == 1 ? "flat, 1 tile per cell" : "flat, 2 tiles per cell") : "ordinary");
     }
     hot_cols -= over_cols; cold_cols += over_cols;
     e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
