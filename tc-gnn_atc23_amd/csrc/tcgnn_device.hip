@@ -104,6 +104,8 @@ struct tcgnn_plan {
         // spmm_cold_planar_kernel adds from the planar image.  0: an ordinary stream.
         int32_t flat_tpc = 0;
         uint32_t* d_flat = nullptr;        // [npairs][16 wavefronts][32 * maxw * flat_tpc words] metadata blocks
+        int32_t* d_wcold_ptr = nullptr;    // [nwg * 16 + 1] the cold remainder as per-wavefront record lists, multiplied inside the flat kernel
+        uint32_t* d_wcold = nullptr;       // [cold tiles][64 words] 32 column ids, 16 mask words, window slot (layouts with LDS to spare)
     };
     CellStream lds[6];   // (kLdsStreams)
     mutable std::atomic<int8_t> lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
@@ -2411,6 +2413,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     // ---- the cold remainder, re-condensed per window for the gather walk
     int64_t cold_tiles = 0, cold_max = 0;
     size_t cold_bytes = 0;
+    std::vector<int64_t> cptr;
     if (e == hipSuccess && cold_cols > 0) {
         const int nwe = p->nw_eff;
         std::vector<uint32_t> coldc((size_t)nwe, 0);
@@ -2423,7 +2426,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         }
         if (e == hipSuccess) e = hipMemcpyAsync(coldc.data(), d_coldcols, coldc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        std::vector<int64_t> cptr((size_t)nwe + 1, 0);
+        cptr.assign((size_t)nwe + 1, 0);
         for (int w = 0; w < nwe; ++w) { cptr[(size_t)w + 1] = cptr[(size_t)w] + (coldc[(size_t)w] + 31) / 32; cold_max = std::max<int64_t>(cold_max, (coldc[(size_t)w] + 31) / 32); }
         cold_tiles = cptr[(size_t)nwe];
         const size_t b_ptr = cptr.size() * sizeof(int64_t), b_c = (size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols * 4, b_m = (size_t)std::max<int64_t>(cold_tiles, 1) * kWinRows * 4;
@@ -2445,6 +2448,40 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         }
         cold_bytes = b_ptr + b_c + b_m;
     }
+    // ---- a flat stream whose layout leaves 16 x NT KB of LDS: the remainder as per-wavefront record lists, multiplied inside the
+    //      flat kernel one tile per range (tcgnn_lds_flat.inc: cold_step) instead of by spmm_cold_planar_kernel afterwards
+    int32_t* d_wcold_ptr = nullptr;
+    uint32_t *d_wcold = nullptr, *d_wlist = nullptr;
+    static const int wcold_enabled = [] { const char* en = getenv("TCGNN_LDS_COLD_INSIDE"); return en ? atoi(en) : 1; }();
+    if (e == hipSuccess && flat_tpc && cold_tiles > 0 && cold_tiles < (1ll << 28) && wcold_enabled && flat_cold_fits(lds_stream_nt(slot), maxw, flat_tpc)) {
+        std::vector<int32_t> wptr((size_t)nwg * kLdsWaves + 1, 0);
+        std::vector<uint32_t> wlist;
+        wlist.reserve((size_t)cold_tiles);
+        for (int g2 = 0; g2 < nwg; ++g2)
+            for (int v = 0; v < kLdsWaves; ++v) {
+                wptr[(size_t)g2 * kLdsWaves + v] = (int32_t)wlist.size();
+                for (int j = 0; j < maxw; ++j) {
+                    const int w = sorder[(size_t)cell_position(g2, v, j, maxw)];
+                    if (w < 0) continue;
+                    for (int64_t t = cptr[(size_t)w]; t < cptr[(size_t)w + 1]; ++t) wlist.push_back((uint32_t)t | ((uint32_t)j << 28));
+                }
+            }
+        wptr[(size_t)nwg * kLdsWaves] = (int32_t)wlist.size();
+        e = hipMalloc(&d_wcold_ptr, wptr.size() * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_wlist, std::max<size_t>(wlist.size(), 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_wcold, std::max<size_t>(wlist.size(), 1) * 64 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_wcold_ptr, wptr.data(), wptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && !wlist.empty()) e = hipMemcpyAsync(d_wlist, wlist.data(), wlist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && !wlist.empty()) {
+            const int64_t nwordsw = (int64_t)wlist.size() * 64;
+            hipLaunchKernelGGL(flat_cold_records_kernel, dim3((unsigned)((nwordsw + 255) / 256)), dim3(256), 0, stream, d_wlist, (int64_t)wlist.size(), d_ccols, d_cmask, d_wcold);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_wlist);
+        if (e != hipSuccess) { (void)hipFree(d_wcold_ptr); (void)hipFree(d_wcold); d_wcold_ptr = nullptr; d_wcold = nullptr; }
+        else cold_bytes += wptr.size() * sizeof(int32_t) + wlist.size() * 256;
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);   // host vectors must outlive their copies
     if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
     (void)hipFree(d_firstq); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
@@ -2452,6 +2489,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     cs.d_order = d_sorder;
     cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
     cs.flat_tpc = flat_tpc; cs.d_flat = d_flat;
+    cs.d_wcold_ptr = d_wcold_ptr; cs.d_wcold = d_wcold;
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
     cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols; cs.cold_max = cold_max;
@@ -2463,7 +2501,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
                         "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
                 slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
                 (long long)ntiles, (long long)cold_tiles, best.mode == kPlaceGlobal ? "longest-first over the graph" : "contiguous blocks");
-    if (verbose && flat_tpc) fprintf(stderr, "[tcgnn]   flat: %d tile(s) per cell, %lld columns beyond the cells' tiles moved to the cold remainder\n", flat_tpc, (long long)over_cols);
+    if (verbose && flat_tpc) fprintf(stderr, "[tcgnn]   flat: %d tile(s) per cell, %lld columns beyond the cells' tiles moved to the cold remainder (%s)\n", flat_tpc, (long long)over_cols,
+                                     d_wcold_ptr ? "multiplied inside the kernel, one tile per range" : "added by spmm_cold_planar_kernel");
     if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
     p->bytes += (flat_tpc ? 0 : (size_t)(ncell_hot + 1) * sizeof(uint32_t)) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
@@ -2545,7 +2584,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             const tcgnn_plan::CellStream& ci = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
             // (a flat stream's remainder is added per pass from the planar image by spmm_cold_planar_kernel: no second image, any
             //  number of passes - but not under the fused dense update, which needs the whole sum before it multiplies)
-            if (ci.flat_tpc) flat_cold = flat_cold || ci.cold_tiles > 0;
+            if (ci.flat_tpc) flat_cold = flat_cold || (ci.cold_tiles > 0 && !ci.d_wcold_ptr);   // (a remainder multiplied inside the flat kernel needs nothing from here)
             else any_cold = any_cold || ci.cold_tiles > 0;
             thin = thin || ci.hot_cols * 2 < ci.hot_cols + ci.cold_cols;
         }
@@ -2608,13 +2647,13 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         const tcgnn_plan::CellStream& cs0 = plan->lds[lds_stream_of(passes[0].nt, passes[0].maxw)];
         KernelTimer timer(plan, stream, cold ? "spmm_lds_kernel + spmm_kernel (cold remainder)" :
-                                        (cs0.flat_tpc ? (cs0.cold_tiles > 0 ? "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)" : "spmm_lds_flat_kernel") : "spmm_lds_kernel"));
+                                        (cs0.flat_tpc ? (cs0.cold_tiles > 0 && !cs0.d_wcold_ptr ? "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)" : "spmm_lds_flat_kernel") : "spmm_lds_kernel"));
         for (int i = 0; i < npass; ++i) {
             const tcgnn_plan::CellStream& cs = plan->lds[lds_stream_of(passes[i].nt, passes[i].maxw)];
             if (cs.flat_tpc) {
-                const bool has_cold = cs.cold_tiles > 0;
+                const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
-                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate};
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_wcold_ptr, cs.d_wcold};
                 HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
@@ -2773,6 +2812,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
+        (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold);
     }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
