@@ -2341,6 +2341,14 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     const int64_t npairs = (int64_t)rlist.size();
     rlist.resize(rlist.size() + 4, 0);
     const int64_t ncell_hot = npairs * per_wg;
+    e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rbase, rbase.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_rlist, rlist.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell_hot + 1) * sizeof(uint32_t), stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_kmap, kmap.data(), kmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rbase, rbase.data(), rbase.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rlist, rlist.data(), rlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     // ---- flat or ordinary (tcgnn_lds_flat.inc): a flat stream gives every cell of a hot pair exactly tpc tiles and sends what
     //      a cell holds beyond 32 tpc columns to the cold remainder.  Taken when that costs few columns (the cold remainder of a
     //      flat stream is added by a latency-bound kernel) and no more tile steps than the ordinary stream's; never with split
@@ -2370,15 +2378,30 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
                               (long long)classic_tiles, (long long)classic_steps, (long long)(npairs * maxw), (long long)over[0], (long long)(2 * npairs * maxw), (long long)over[1],
                               flat_tpc ? (flat_tpc == 1 ? "flat, 1 tile per cell" : "flat, 2 tiles per cell") : "ordinary");
     }
+    if (flat_tpc && !getenv("TCGNN_LDS_FLAT")) {
+        // ... nor where ONE window would leave a long remainder behind (a hub row: its cells overflow in every range, and the
+        // remainder of a window is one wavefront's serial work - a 24 k-degree hub cost the flat walk 0.72 ms against 0.61):
+        // the remainder is counted with the flat cap before anything is built
+        uint32_t* d_trial = nullptr;
+        std::vector<uint32_t> trial((size_t)p->nw_eff, 0u);
+        e = hipMalloc(&d_trial, trial.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_trial, 0, trial.size() * sizeof(uint32_t), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_trial, (uint32_t)(32 * flat_tpc));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(trial.data(), d_trial, trial.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_trial);
+        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
+        uint32_t worst = 0;
+        for (uint32_t c : trial) worst = std::max(worst, (c + 31u) / 32u);
+        if (worst > 16u) {
+            if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: ordinary after all - one window would leave %u cold tiles behind\n", slot, worst);
+            flat_tpc = 0; over_cols = 0;
+        }
+    }
     hot_cols -= over_cols; cold_cols += over_cols;
-    e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_rbase, rbase.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_rlist, rlist.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell_hot + 1) * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_kmap, kmap.data(), kmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rbase, rbase.data(), rbase.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rlist, rlist.data(), rlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
     if (ncell > 0) hipLaunchKernelGGL(cell_compact_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, npairs_all, per_wg, d_cnt);
     std::vector<uint32_t> cnt((size_t)ncell_hot + 1);
     e = hipGetLastError();
