@@ -22,8 +22,13 @@
  *   - Device pointers are BORROWED for the duration of the call (the plan borrows the five legacy
  *     arrays for its lifetime, see tcgnn_plan_create); outputs are caller-allocated.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All device
- *     work is enqueued asynchronously on it; only tcgnn_plan_create / tcgnn_preprocess_gpu
- *     synchronise (once, to size their outputs).
+ *     work is enqueued asynchronously on it.  What synchronises the stream: tcgnn_plan_create and
+ *     tcgnn_preprocess_gpu (to size their outputs), tcgnn_plan_prepare, and - ONLY for a feature width
+ *     tcgnn_plan_prepare was not called for - the first tcgnn_spmm / tcgnn_spmm_fused / tcgnn_spmm_gemm
+ *     call of that width on a plan whose time model picks the LDS-resident kernel (it builds the
+ *     width's cell stream: allocations, a few count-and-place round trips).  Call tcgnn_plan_prepare
+ *     for every width a model uses and no hot-path call synchronises, allocates or - inside a HIP
+ *     graph capture - takes a different walk than it would outside one.
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
  *     TCGNN_kernel.cu:420).
@@ -138,6 +143,10 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
                               const int32_t* d_edgeToRow, int32_t num_rows, int32_t num_cols,
                               int32_t row_offset, int64_t num_edges, int32_t num_windows,
                               void* stream, tcgnn_plan** plan_out);
+/* Builds, now, whatever the hot path would otherwise build on its first call at feature width D (the cell stream(s) of the
+ * LDS-resident kernel where the plan's time model picks it for that width; nothing for the gather walks).  Synchronises
+ * `stream`.  Idempotent; widths are independent.  No counterpart in the reference (its kernels re-derive their tiles per launch). */
+int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream);
 int tcgnn_plan_destroy(tcgnn_plan* plan);
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
 

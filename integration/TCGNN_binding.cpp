@@ -8,6 +8,8 @@
 // as a second backend next to the ctypes one (tc-gnn_atc23_amd/TCGNN.py).
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
+#include <hip/hip_runtime_api.h>
 
 #include <cstdio>
 #include <list>
@@ -27,6 +29,18 @@ void tcgnn_check(int st, const char* what) {
 }
 
 void* current_stream(const torch::Tensor& t) { return c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+// the extension works on the device its tensors live on, not on whatever device happens to be current (plan allocations and
+// kernel launches follow the current device) - what torch's own operators do with a device guard (r2 ADVICE)
+using DeviceGuard = c10::DeviceGuard;   // (dispatches to the HIP guard registered for "cuda" tensors on ROCm)
+
+// X must hold one row per node of the graph: a shorter matrix would be read out of bounds by the staging pass and the gathers
+// (the reference indexes input by the same row ids, TCGNN_kernel.cu:417-427, without a check)
+void check_rows(const torch::Tensor& input, const torch::Tensor& nodePointer) {
+  TORCH_CHECK(input.dim() == 2, "input must be a 2-D [num_nodes, dim] matrix");
+  TORCH_CHECK(nodePointer.numel() >= 1 && input.size(0) == nodePointer.numel() - 1, "input has ", input.size(0), " rows, the graph has ",
+              nodePointer.numel() - 1, " nodes");
+}
 
 // One plan per graph.  The reference hands the same five tensors to every call (gnn_conv.py:31,56), so the packed tile stream
 // is built at first sight and found again by (address, length, in-place version) of each; the entry keeps the tensors alive,
@@ -58,7 +72,7 @@ tcgnn_plan* plan_for(const torch::Tensor& nodePointer, const torch::Tensor& edge
               "tcgnn_plan_create");
   cache.push_front(std::move(e));
   while (cache.size() > kPlanCacheSize) {
-    c10::hip::getCurrentHIPStream(nodePointer.get_device()).synchronize();   // kernels still reading the evicted plan finish first
+    (void)hipDeviceSynchronize();   // kernels still reading the evicted plan - on ANY stream - finish first
     tcgnn_plan_destroy(cache.back().plan);
     cache.pop_back();
   }
@@ -85,7 +99,9 @@ std::vector<torch::Tensor> spmm_forward(torch::Tensor input, torch::Tensor nodeP
   CHECK_INPUT(input); CHECK_INPUT(nodePointer); CHECK_INPUT(edgeList);
   CHECK_INPUT(blockPartition); CHECK_INPUT(edgeToColumn); CHECK_INPUT(edgeToRow);
   TORCH_CHECK(input.scalar_type() == torch::kFloat32, "expected scalar type Float");
-  auto output = torch::empty_like(input);                          // fully overwritten by the kernels
+  check_rows(input, nodePointer);
+  DeviceGuard guard(input.device());
+  auto output = torch::empty_like(input);                          // fully overwritten by the kernels (every row is a node's)
   if (input.numel() == 0) return {output};
   auto* plan = plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow);
   const int D = (int)input.size(1);
@@ -102,6 +118,8 @@ std::vector<torch::Tensor> spmm_forward_AGNN(torch::Tensor input, torch::Tensor 
   CHECK_INPUT(blockPartition); CHECK_INPUT(edgeToColumn); CHECK_INPUT(edgeToRow);
   TORCH_CHECK(input.scalar_type() == torch::kFloat32 && edgeAttention.scalar_type() == torch::kFloat32, "expected scalar type Float");
   TORCH_CHECK(edgeAttention.numel() >= edgeList.numel(), "edgeAttention holds fewer values than there are edges");
+  check_rows(input, nodePointer);
+  DeviceGuard guard(input.device());
   auto output = torch::empty_like(input);
   if (input.numel() == 0) return {output};
   auto* plan = plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow);
@@ -119,6 +137,8 @@ std::vector<torch::Tensor> sddmm_forward(torch::Tensor input, torch::Tensor node
   CHECK_INPUT(input); CHECK_INPUT(nodePointer); CHECK_INPUT(edgeList);
   CHECK_INPUT(blockPartition); CHECK_INPUT(edgeToColumn); CHECK_INPUT(edgeToRow);
   TORCH_CHECK(input.scalar_type() == torch::kFloat32, "expected scalar type Float");
+  check_rows(input, nodePointer);
+  DeviceGuard guard(input.device());
   auto ef = torch::empty({edgeList.size(0)}, input.options());
   if (edgeList.size(0) == 0) return {ef};
   if (input.size(1) == 0) return {ef.zero_()};
@@ -156,6 +176,7 @@ void preprocess_gpu(torch::Tensor edgeList, torch::Tensor nodePointer, int num_n
     TORCH_CHECK(t->scalar_type() == torch::kInt32, "expected scalar type Int");
   TORCH_CHECK(nodePointer.numel() >= (int64_t)num_nodes + 1, "nodePointer must hold num_nodes + 1 entries");
   TORCH_CHECK(edgeToColumn.numel() >= edgeList.numel() && edgeToRow.numel() >= edgeList.numel(), "edgeToColumn / edgeToRow are shorter than edgeList");
+  DeviceGuard guard(edgeList.device());
   int64_t tc_blocks = 0;
   tcgnn_check(tcgnn_preprocess_gpu(edgeList.data_ptr<int>(), nodePointer.data_ptr<int>(), num_nodes, edgeList.numel(), blockSize_h, blockSize_w,
                                    blockPartition.data_ptr<int>(), blockPartition.numel(), edgeToColumn.data_ptr<int>(),
@@ -165,7 +186,10 @@ void preprocess_gpu(torch::Tensor edgeList, torch::Tensor nodePointer, int num_n
 }
 
 void clear_plan_cache() {
-  for (auto& e : plan_cache()) tcgnn_plan_destroy(e.plan);
+  for (auto& e : plan_cache()) {
+    if (!e.keep.empty() && e.keep[0].is_cuda()) { DeviceGuard guard(e.keep[0].device()); (void)hipDeviceSynchronize(); }   // nothing may still be reading the plan
+    tcgnn_plan_destroy(e.plan);
+  }
   plan_cache().clear();
 }
 

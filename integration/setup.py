@@ -24,8 +24,8 @@ setup(
         sources=["TCGNN_binding.cpp"],
         include_dirs=[os.path.join(ROOT, "include"), os.path.join(ROCM, "include")],
         define_macros=[("__HIP_PLATFORM_AMD__", "1"), ("USE_ROCM", "1")],
-        library_dirs=[LIBDIR],
-        libraries=["tcgnn_hip", "c10_hip", "torch_hip"],
+        library_dirs=[LIBDIR, os.path.join(ROCM, "lib")],
+        libraries=["tcgnn_hip", "c10_hip", "torch_hip", "amdhip64"],
         extra_compile_args=["-O2", "-Wno-deprecated-declarations"],
         extra_link_args=["-Wl,-rpath,$ORIGIN/../tc-gnn_atc23_amd/lib", "-Wl,-rpath," + LIBDIR],
     )],

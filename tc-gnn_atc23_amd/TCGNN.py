@@ -159,6 +159,18 @@ def plan_info(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
     return {f: getattr(info, f) for f, _ in info._fields_}
 
 
+def prepare(widths, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+    """Not part of the reference API: build, now, what the hot path would otherwise build at its first call of each feature width
+    in `widths` (tcgnn_plan_prepare: the cell streams of the LDS-resident kernel where the plan's time model picks it).  After it
+    no forward / backward call of those widths synchronises or allocates inside the library, and a call captured into a HIP graph
+    takes the walk it would take outside one.  The harness calls it with the model's widths before the dry epochs."""
+    plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    dev = nodePointer.device
+    with torch.cuda.device(dev):
+        for d in sorted({int(w) for w in widths if int(w) >= 1}):
+            _c.check(_c.lib.tcgnn_plan_prepare(plan, d, _stream_handle(dev)), "tcgnn_plan_prepare")
+
+
 def kernel_timing(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, max_calls=None):
     """Not part of the reference API.  kernel_timing(meta..., max_calls=K) arms HIP-event timing of
     the main kernel for the next K calls on this graph; kernel_timing(meta...) (no max_calls) waits

@@ -3032,6 +3032,24 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info) {
     return TCGNN_OK;
 }
 
+int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream_v) {
+    if (!plan || D < 1) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_prepare: null plan or D < 1");
+    if (plan->nw_eff <= 0 || plan->N == 0) return TCGNN_OK;
+    const int dpad = round_up(D, 16);
+    if (!(g_spmm_mode == 3 || (g_spmm_mode == 0 && plan->total_wb > kSmallMaxTiles && lds_chosen(plan, dpad)))) return TCGNN_OK;   // the gather walks need nothing built
+    if ((int64_t)(dpad / 16) * ((int64_t)plan->Nc + 1) * 32 >= ((int64_t)1 << 32)) return TCGNN_OK;
+    LdsPass passes[2];
+    const int np = lds_passes(dpad, passes);
+    for (int i = 0; i < np; ++i) {
+        const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
+        if (plan->lds[slot].nranges > 0) continue;
+        const int rc = build_lds_cells(plan, static_cast<hipStream_t>(stream_v), slot);
+        if (rc && g_spmm_mode == 3) return rc;
+        if (rc && dpad / 16 <= 64) plan->lds_choice[dpad / 16] = 0;   // (as the hot path would: no memory for the stream -> the gather walks)
+    }
+    return TCGNN_OK;
+}
+
 int tcgnn_set_spmm_mode(int32_t mode) {
     if (mode < 0 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked), 3 (LDS-resident ranges) or 4 (single-launch fp32 kernel)");
     g_spmm_mode = mode;
