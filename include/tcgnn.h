@@ -29,6 +29,14 @@
  *     width's cell stream: allocations, a few count-and-place round trips).  Call tcgnn_plan_prepare
  *     for every width a model uses and no hot-path call synchronises, allocates or - inside a HIP
  *     graph capture - takes a different walk than it would outside one.
+ *   - Operand range.  The MFMA kernels read a power-of-two-scaled fp16 image of X (one scale per matrix and call): every
+ *     element within 2^28 of the largest is rounded bit-for-bit like the reference's TF32 operand (TCGNN_kernel.cu:438-444),
+ *     smaller ones lose mantissa bits and, 2^39 below the maximum, are flushed - an absolute error of at most max|X| * 2^-39
+ *     per element.  A matrix (or edge-value array) that holds BOTH a magnitude >= 2^8 and a nonzero one more than 2^28 below
+ *     its maximum is routed - by a test on the device, no read-back - to fp32 fallback kernels that keep fp32's exponent like
+ *     the reference does (slow, correct for any magnitudes); everything else stays on the MFMA path, where the bound above is
+ *     below 1e-9.  Images the CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
+ *     header bytes 4 .. 255 must be zero.
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
  *     TCGNN_kernel.cu:420).

@@ -131,7 +131,8 @@ struct KernelTimer {
             else p->ev_used.store((int)p->ev.size() / 2, std::memory_order_relaxed);   // full: stay saturated, never wrap
         }
     }
-    ~KernelTimer() { if (slot >= 0) (void)hipEventRecord(p->ev[2 * slot + 1], s); }
+    void stop() { if (slot >= 0) { (void)hipEventRecord(p->ev[2 * slot + 1], s); slot = -1; } }   // (before the range guard's fallback launch: not part of the kernel)
+    ~KernelTimer() { stop(); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -148,6 +149,23 @@ __device__ __forceinline__ int scale_exp_from_bits(uint32_t b) {
 }
 __device__ __forceinline__ float relu_if(int on, float v) { return on ? fmaxf(v, 0.0f) : v; }
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// ---- the within-matrix range guard -------------------------------------------------------
+// The fp16 operand image carries ONE power-of-two scale per matrix: an element more than 2^28 below the largest loses mantissa
+// bits (fp16 subnormal) and one more than 2^39 below it is flushed to zero, where the reference's TF32 keeps fp32's exponent
+// (TCGNN_kernel.cu:438-444).  The absolute error that leaves per element is <= max|X| * 2^-39, which stays far inside the
+// contract's |d| <= 1e-3 max(1, |ref|) whenever max|X| < 2^8 - whatever the small elements are.  A matrix that holds BOTH an
+// element >= 2^8 and a nonzero one more than 2^28 below the maximum is "wide": for it every fp16-path kernel returns at once and
+// a fallback kernel launched behind it (plain fp32, operands rounded exactly like the reference's, CSR order) does the work; for
+// every other matrix the fallback returns at once.  The decision is made on the device from the staging pass's header words -
+// word k: bits of max |.| (k = 0: X, 1: edge values), word k + 2: 0x7f800000 - bits of the smallest nonzero |.| (0: none seen) -
+// so no call synchronises or reads anything back.
+__device__ __forceinline__ bool range_is_wide(const uint32_t* hdr, int k) {
+    const uint32_t mx = hdr[k], mi = hdr[k + 2];
+    if (mi == 0u || mx == 0u || mx >= 0x7f800000u) return false;
+    const int emax = (int)(mx >> 23), emin = (int)((0x7f800000u - mi) >> 23);
+    return emax >= 127 + 8 && emax - emin > 28;
+}
 
 // Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
 // wmma::__float_to_tf32 (cvt.rna.tf32.f32, TCGNN_kernel.cu:441-444) does.  The result has at most
@@ -281,9 +299,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
 // ------------------------------------------------------------------------------------------
 // staging: absmax + fp32 -> scaled fp16 copy with a zero sentinel row
 // ------------------------------------------------------------------------------------------
+// (out_lo: where the smallest nonzero magnitude is recorded for the range guard, nullptr: not wanted - images a caller stages
+//  itself, tcgnn_stage_absmax, carry no such word and are never "wide")
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, int64_t n,
-                                                     uint32_t* out) {
-    uint32_t m = 0;
+                                                     uint32_t* out, uint32_t* out_lo) {
+    uint32_t m = 0, lo = 0;   // lo: 0x7f800000 - bits of the smallest nonzero finite magnitude (larger = smaller; 0 = none): range_is_wide
+    auto see = [&](float f) {
+        const uint32_t b = __float_as_uint(f) & 0x7fffffffu;
+        m = max(m, b);
+        lo = max(lo, (b - 1u < 0x7f7fffffu) ? 0x7f800000u - b : 0u);   // (b - 1 wraps for 0: zero, Inf and NaN do not count)
+    };
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
@@ -291,31 +316,35 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
         const float4* p4 = reinterpret_cast<const float4*>(p);
         for (int64_t k = gid; k < n4; k += gsz) {
             const float4 v = p4[k];
-            m = max(m, __float_as_uint(v.x) & 0x7fffffffu);
-            m = max(m, __float_as_uint(v.y) & 0x7fffffffu);
-            m = max(m, __float_as_uint(v.z) & 0x7fffffffu);
-            m = max(m, __float_as_uint(v.w) & 0x7fffffffu);
+            see(v.x); see(v.y); see(v.z); see(v.w);
         }
-        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) see(p[k]);
     } else {
-        for (int64_t k = gid; k < n; k += gsz) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+        for (int64_t k = gid; k < n; k += gsz) see(p[k]);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, off)); }
     // one atomic per workgroup: a single word saturates near 88 atomics/us (MI355X_MICROARCH.md
     // "dequeue"), so per-wave atomics from a 2048-block grid alone cost ~90 us
-    __shared__ uint32_t wmax[4];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __shared__ uint32_t wmax[4], wlo[4];
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wlo[threadIdx.x >> 6] = lo; }
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
+        if (lo && out_lo) atomicMax(out_lo, lo);
     }
 }
 
 // absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
-__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out) {
-    uint32_t m = 0;
+__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo) {
+    uint32_t m = 0, lo = 0;
+    auto see = [&](float f, float gt) {
+        const uint32_t b = gt > 0.0f ? __float_as_uint(f) & 0x7fffffffu : 0u;
+        m = max(m, b);
+        lo = max(lo, (b - 1u < 0x7f7fffffu) ? 0x7f800000u - b : 0u);
+    };
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gate)) & 15) == 0) {   // (scalar loads: 85 us for 2 x 60 MB)
@@ -324,25 +353,22 @@ __global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restri
         const float4* g4 = reinterpret_cast<const float4*>(gate);
         for (int64_t k = gid; k < n4; k += gsz) {
             const float4 v = p4[k], gt = g4[k];
-            m = max(m, gt.x > 0.0f ? __float_as_uint(v.x) & 0x7fffffffu : 0u);
-            m = max(m, gt.y > 0.0f ? __float_as_uint(v.y) & 0x7fffffffu : 0u);
-            m = max(m, gt.z > 0.0f ? __float_as_uint(v.z) & 0x7fffffffu : 0u);
-            m = max(m, gt.w > 0.0f ? __float_as_uint(v.w) & 0x7fffffffu : 0u);
+            see(v.x, gt.x); see(v.y, gt.y); see(v.z, gt.z); see(v.w, gt.w);
         }
-        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz)
-            if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) see(p[k], gate[k]);
     } else {
-        for (int64_t k = gid; k < n; k += gsz)
-            if (gate[k] > 0.0f) m = max(m, __float_as_uint(p[k]) & 0x7fffffffu);
+        for (int64_t k = gid; k < n; k += gsz) see(p[k], gate[k]);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    __shared__ uint32_t wmax[4];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, off)); }
+    __shared__ uint32_t wmax[4], wlo[4];
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wlo[threadIdx.x >> 6] = lo; }
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
+        if (lo && out_lo) atomicMax(out_lo, lo);
     }
 }
 
@@ -717,6 +743,7 @@ struct TileWalker {
 // spent 24 v_accvgpr_* moves per tile shuffling them)
 template <int NT, int WAVES, bool VAL>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(const SpmmArgs a) {
+    if (range_is_wide(a.hdr, 0) || (VAL && range_is_wide(a.hdr, 1))) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -862,6 +889,7 @@ __global__ void bucket_ptr_kernel(const int64_t* __restrict__ wb_ptr, const int3
 
 template <int NT, int MAXW, bool VAL>
 __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(const SpmmBlockedArgs b) {
+    if (range_is_wide(b.base.hdr, 0) || (VAL && range_is_wide(b.base.hdr, 1))) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SpmmArgs& a = b.base;
     const int lane = threadIdx.x & 63;
@@ -980,6 +1008,7 @@ static constexpr int sddmm_wave_lds(int ks) { return sddmm_nbuf(ks) * (2 * ks * 
 // and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
 template <int KS, int WAVES, bool BLOCKED>
 __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(const SddmmArgs a) {
+    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
     constexpr int WAVE_LDS = sddmm_wave_lds(KS);
@@ -1174,6 +1203,7 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
 // Run-time-K variant for D > 128: window rows are re-read per tile (L1-resident), ordinary loads.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs a) {
+    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -1266,6 +1296,7 @@ static constexpr int agnn_wave_lds(int ks, bool bwd) {
 //           ranges in step, as spmm_blocked_kernel does, so the gathered rows stay L2-resident.
 template <int NT, int WAVES, bool BWD, int MAXW>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
+    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = (NT + 1) / 2;
     constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
@@ -1699,6 +1730,107 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restric
     }
 }
 
+// ---- fallbacks behind the range guard (range_is_wide): launched behind every fp16-path kernel, they return at once unless the
+//      staged matrix is "wide".  Plain fp32, CSR order, operands rounded to a 10-bit mantissa exactly like the reference's
+//      (round_rna10) with fp32's full exponent: correct for any magnitudes, far from fast - a wide matrix is a rare input.
+// Y[row] = [relu] sum_e v_e * rna(X'[col e]) with v_e = 1 (binary), rna(val[e]) or rna(fl32(w * val[e])) (the AGNN edge weights);
+// X' = X where gate > 0 (the fused ReLU backward mask).  ldx / ldy: row strides (column blocks of wider matrices).
+__global__ __launch_bounds__(256) void spmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, int use_val_word, const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ wscale,
+                                                                 const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int32_t N, int32_t D,
+                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe) {
+    if (!(range_is_wide(hdr, 0) || (use_val_word && range_is_wide(hdr, 1)))) return;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+    const float w = wscale ? wscale[0] : 1.0f;
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+        for (int64_t e = e0; e < e1; ++e) {
+            if (dedupe) {   // binary A on a non-canonical row: an edge listed twice counts once (TCGNN_kernel.cu:405)
+                bool dup = false;
+                for (int64_t e2 = e0; e2 < e; ++e2) dup = dup || col[e2] == col[e];
+                if (dup) continue;
+            }
+            const int64_t xi = (int64_t)col[e] * ldx + d;
+            float x = X[xi];
+            if (gate && !(gate[xi] > 0.0f)) x = 0.0f;
+            const float v = val ? round_rna10(wscale ? w * val[e] : val[e]) : 1.0f;
+            s += v * round_rna10(x);
+        }
+        Y[row * ldy + d] = relu_if(relu, s);
+    }
+}
+// Y[row] = [relu] ((A X)[row]) W: the aggregated row goes through LDS, then every lane takes output columns (D_in, D_out <= 128)
+__global__ __launch_bounds__(256) void spmm_gemm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                      const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int32_t N,
+                                                                      int32_t Din, int32_t Dout, int32_t relu) {
+    if (!range_is_wide(hdr, 0)) return;
+    __shared__ float agg[4][128];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row < N) {
+        const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
+        for (int d = lane; d < Din; d += 64) {
+            float s = 0.f;
+            for (int64_t e = e0; e < e1; ++e) s += round_rna10(X[(int64_t)col[e] * Din + d]);
+            agg[wv][d] = s;
+        }
+    }
+    __syncthreads();
+    if (row >= N) return;
+    for (int o = lane; o < Dout; o += 64) {
+        float s = 0.f;
+        for (int k = 0; k < Din; ++k) s = fmaf(agg[wv][k], W[(int64_t)k * Dout + o], s);
+        Y[row * Dout + o] = relu_if(relu, s);
+    }
+}
+// ef[e] = <rna(X[row e]), rna(X[col e])>; absmax (optional): bits of max |ef| (the fused AGNN forward records it for its backward)
+__global__ __launch_bounds__(256) void sddmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                  const float* __restrict__ X, float* __restrict__ ef, int32_t N, int32_t D, int32_t row_off,
+                                                                  uint32_t* __restrict__ absmax) {
+    if (!range_is_wide(hdr, 0)) return;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = X + (row + row_off) * D;
+    uint32_t m = 0;
+    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+        const float* xc = X + (int64_t)col[e] * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) { ef[e] = s; m = max(m, __float_as_uint(s) & 0x7fffffffu); }
+    }
+    if (absmax && lane == 0 && m) atomicMax(absmax, m);
+}
+// the fused AGNN backward's attention-weight gradient: partial[k] = sum over windows k, k + gridDim.x, ... of
+// sum_e <rna(dY[row e]), rna(dY[col e])> * (float)col(e), rows and edges in order (deterministic), as doubles for agnn_reduce_kernel
+__global__ __launch_bounds__(64) void agnn_dw_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                   const float* __restrict__ X, double* __restrict__ partial, int32_t N, int32_t D, int32_t row_off, int32_t nw) {
+    if (!range_is_wide(hdr, 0)) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+        for (int r = 0; r < kWinRows; ++r) {
+            const int64_t row = (int64_t)w * kWinRows + r;
+            if (row >= N) break;
+            const float* xr = X + (row + row_off) * D;
+            for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+                const float* xc = X + (int64_t)col[e] * D;
+                float s = 0.f;
+                for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                acc += (double)s * (double)(float)col[e];
+            }
+        }
+    }
+    if (lane == 0) partial[blockIdx.x] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // launch tables
 // ------------------------------------------------------------------------------------------
@@ -1853,12 +1985,12 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2);
     }
     if (d_val && plan->E > 0 && !block_of_wider) {
         const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3);
     }
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
@@ -2627,11 +2759,11 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipMemsetAsync(whdr, 0, 16, stream));
         const int64_t nx = (int64_t)plan->Nc * D;
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2);
         if (d_val && plan->E > 0) {
             const int g2 = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1);
+            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3);
         }
         HIP_TRY(hipGetLastError());
         for (int c0 = 0; c0 < D; c0 += kMaxGatherBlockDims) {
@@ -2651,6 +2783,17 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         if (rc) return rc;
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
+    // the range guard's fallback, launched behind the fp16-path kernels of this call (returns at once unless the staged matrix is
+    // "wide": range_is_wide).  An image the caller staged itself carries no range words: no guard.
+    auto wide_fallback = [&]() -> int {
+        if (d_staged) return TCGNN_OK;
+        const unsigned grid = (unsigned)((plan->N + 3) / 4);
+        if (d_W) hipLaunchKernelGGL(spmm_gemm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_W, d_Y, plan->N, D, D_out, relu);
+        else hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, d_val ? 1 : 0, plan->rowptr, plan->col, d_val, (const float*)nullptr, d_X, d_gate, d_Y,
+                                plan->N, D, (int64_t)ld, (int64_t)ld, relu, (!d_val && !plan->canonical) ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        return TCGNN_OK;
+    };
     if (lds) {
         int total_chunks = 0;
         for (int i = 0; i < npass; ++i) total_chunks += passes[i].nchunks;
@@ -2703,7 +2846,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(false, waves, 8, a, plan->nw_eff, nfull, stream)); }
             if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(false, waves, rem, a, plan->nw_eff, 1, stream)); }
         }
-        return TCGNN_OK;
+        timer.stop();
+        return wide_fallback();
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
                image_is_big(plan->Nc, pitch), d_W, D_out, 0};
@@ -2736,11 +2880,13 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         };
         if (nfull) { b.base.chunk0 = 0; const int n = wgs(8); HIP_TRY(launch_blocked_any(d_val != nullptr, 8, b, n, nfull, stream)); }
         if (rem) { b.base.chunk0 = nfull; const int n = wgs(rem); HIP_TRY(launch_blocked_any(d_val != nullptr, rem, b, n, 1, stream)); }
-        return TCGNN_OK;
+        timer.stop();
+        return wide_fallback();
     }
     if (nfull) { a.chunk0 = 0; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, 8, a, plan->nw_eff, nfull, stream)); }
     if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(d_val != nullptr, plan->waves, rem, a, plan->nw_eff, 1, stream)); }
-    return TCGNN_OK;
+    timer.stop();
+    return wide_fallback();
 }
 
 static bool agnn_supported(const tcgnn_plan* plan, int32_t D) {
@@ -2803,6 +2949,14 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
             e = bwd ? launch_agnn<1, true, 0>(nt, a, nwg, stream) : launch_agnn<1, false, 0>(nt, a, nwg, stream);
         }
         HIP_TRY(e);
+    }
+    {   // the range guard's fallbacks (each returns at once unless the staged matrix is "wide"): the same two products in fp32
+        const unsigned grid = (unsigned)((plan->N + 3) / 4);
+        if (!bwd) hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_ef, plan->N, D, plan->row_off, d_absmax);
+        hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, 0, plan->rowptr, plan->col, (const float*)d_ef, d_w, d_X, (const float*)nullptr, d_Y,
+                           plan->N, D, (int64_t)D, (int64_t)D, 0, 0);
+        if (bwd) hipLaunchKernelGGL(agnn_dw_wide_fallback_kernel, dim3((unsigned)nwg), dim3(64), 0, stream, hdr, plan->rowptr, plan->col, d_X, partial, plan->N, D, plan->row_off, plan->nw_eff);
+        HIP_TRY(hipGetLastError());
     }
     if (bwd) {
         hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nwg, d_dw);
@@ -3132,7 +3286,7 @@ int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stre
     if (n < 0 || (n > 0 && !d_X) || !d_word) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_absmax: null argument");
     if (n == 0) return TCGNN_OK;
     const int grid = (int)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }
@@ -3201,6 +3355,11 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         e = plan->waves == 4 ? launch_sddmm_ks<4, false>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1, false>(ks, a, plan->nw_eff, stream);
     }
     HIP_TRY(e);
+    timer.stop();
+    // (the range guard's fallback: returns at once unless X is "wide")
+    hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3((unsigned)((plan->N + 3) / 4)), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_ef, plan->N, D, plan->row_off,
+                       (uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }
 

@@ -417,6 +417,14 @@ class GINConv(torch.nn.Module):
         self.weights = torch.nn.Parameter(torch.randn(input_dim, output_dim))
 
     def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow):
+        # inference (no gradient will be asked for: grad mode off, or neither operand requires one) takes the one-launch form
+        # (A X) W of tcgnn_spmm_gemm - decided HERE, from the grad mode: inside a Function `needs_input_grad` only mirrors
+        # `requires_grad`, so under model.eval() + torch.no_grad() with ordinary Parameters it never fired (r2 ADVICE).
+        # forward_gemm is inference-only: it has no backward.
+        b = backend()
+        if ((not torch.is_grad_enabled() or not (X.requires_grad or self.weights.requires_grad)) and X.is_cuda
+                and hasattr(b, "forward_gemm") and max(self.weights.shape) <= getattr(b, "GEMM_FUSED_MAX_DIM", 128)):
+            return b.forward_gemm(X, self.weights.detach(), row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)[0]
         return TCGNNFunction_GIN.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)
 
 

@@ -922,6 +922,70 @@ def test_range_robustness_beyond_fp16(dev, T):
     assert not Z.any()
 
 
+def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
+    """VERDICT r02 item 6 / SURVEY.md 7.3: ONE power-of-two scale per matrix loses the elements more than 2^28 below the largest
+    (fp16 subnormals, then zero) where the reference's TF32 keeps fp32's exponent (TCGNN_kernel.cu:438-444).  O(1e-3) data with one
+    1e6 row: rows that never touch the outlier must still come out to accumulation-order accuracy, which the fp16 image cannot
+    deliver (its quantum there is 2e-6 per element) - the range guard routes the call, on the device, to the fp32 fallback kernels.
+    A matrix whose maximum is small (< 2^8) keeps the fp16 path whatever its small elements are: what they lose is below 1e-9."""
+    rp, col = graphs.uniform_graph(4000, 100, seed=5)        # > kSmallMaxTiles wide blocks: the fp16 walks, not the small fp32 kernel
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    assert T.plan_info(*meta)["wide_blocks"] > 8192
+    n, D = len(rp) - 1, 64
+    rng = np.random.default_rng(11)
+    att = rng.standard_normal(len(col)).astype(np.float32)
+    for name, outlier, wide in (("outlier 1e6 over 1e-3 data", 1e6, True), ("1e-14 specks in O(1) data", None, False)):
+        X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32)
+        if outlier is not None:
+            X[1234] = outlier * (1.0 + rng.random(D).astype(np.float32))
+        else:
+            X *= 1e3                                             # unit scale, max ~ 4.5 < 2^8: never "wide"
+            X[::7] *= 1e-14
+        tX = torch.from_numpy(X).to(dev)
+        tatt = torch.from_numpy(att).to(dev).view(1, -1)
+        Y = T.forward(tX, *meta)[0].cpu().numpy()
+        Yr = T.forward_fused(tX, *meta, relu=True)[0].cpu().numpy()
+        Yv = T.forward_AGNN(tX, meta[0], meta[1], tatt, *meta[2:])[0].cpu().numpy()
+        ef = T.forward_ef(tX, *meta)[0].cpu().numpy()
+        ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); r64, a64 = O.spmm_f64(X, rp, col)
+        refv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, av64 = O.spmm_f64(X, rp, col, att)
+        refe = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, ae64 = O.sddmm_f64(X, rp, col)
+        # rows that never touch the outlier: the tight bound is relative to THEIR sum of |terms| (~0.1), not to the matrix maximum
+        err = {"spmm": np.abs(Y - ref) / (a64 + 1e-30), "spmm+relu": np.abs(Yr - np.maximum(ref, 0)) / (a64 + 1e-30),
+               "spmm_val": np.abs(Yv - refv) / (av64 + 1e-30), "sddmm": np.abs(ef - refe) / (ae64 + 1e-30)}
+        for k, v in err.items():
+            if wide:
+                assert v.max() <= 4 * TIGHT, "%s, %s: %.3e relative to the row's own terms" % (name, k, v.max())
+        # the north star's bar holds either way
+        for got, want in ((Y, ref), (Yv, refv), (ef, refe)):
+            assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= TOL
+        if wide:   # the fp16 image alone would miss by orders of magnitude: the test is sensitive to the fallback
+            small_rows = np.abs(ref).max(axis=1) < 1.0
+            assert small_rows.sum() > n // 2 and err["spmm"][small_rows].max() <= 4 * TIGHT
+        # the fused AGNN pair, forward and backward, against the separate operators' definitions
+        w = np.float32(0.75)
+        tw = torch.tensor([w], device=dev)
+        Yf, ef_f, efm = T.agnn_fused_forward(tX, meta[0], meta[1], tw, *meta[2:])
+        if wide:
+            assert (np.abs(ef_f.cpu().numpy() - refe) / (ae64 + 1e-30)).max() <= 4 * TIGHT
+        assert (np.abs(ef_f.cpu().numpy() - refe) / np.maximum(1.0, np.abs(refe))).max() <= TOL
+        # (the aggregation is checked on the scores the kernel itself produced: a score that differs from the oracle's by
+        #  accumulation noise can round to the neighbouring 10-bit edge weight, a 2^-11 step that no summation order explains)
+        att_ref = (w * ef_f.cpu().numpy()).astype(np.float32)
+        refYf = O.spmm_val(X, rp, col, att_ref, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, aYf = O.spmm_f64(X, rp, col, att_ref)
+        def close(got):   # wide: to accumulation accuracy of every row's OWN terms (ef carries its noise into att: x 64); else the bar
+            if wide:
+                assert (np.abs(got - refYf) / (aYf + 1e-30)).max() <= 256 * TIGHT
+            assert (np.abs(got - refYf) / np.maximum(1.0, np.abs(refYf))).max() <= TOL
+        close(Yf.cpu().numpy())
+        G, dw = T.agnn_fused_backward(tX, meta[0], meta[1], tw, ef_f, efm, *meta[2:])
+        want_dw = float((refe.astype(np.float64) * col.astype(np.float64)).sum())
+        scale_dw = float((ae64 * col).sum()) + 1.0
+        assert abs(float(dw) - want_dw) <= 1e-5 * scale_dw, (float(dw), want_dw)
+        close(G.cpu().numpy())
+    T.clear_plan_cache()
+
+
 def test_plan_cache_follows_in_place_mutation_and_streams(dev, T):
     rp, col = graphs.uniform_graph(300, 6, seed=8)
     (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
@@ -1136,8 +1200,17 @@ def test_gcn_layer_that_aggregates_first_trains_like_the_reference_order(dev, T)
     yb.backward(dY)
     assert torch.equal(ga, xb.grad) and torch.equal(gwa, conv.weights.grad)
     gin = L.GINConv(64, 41).to(dev)
-    with torch.no_grad():
-        y_fused = gin(x, *meta)
+    calls = []
+    real_gemm = T.forward_gemm
+    T.forward_gemm = lambda *a, **k: (calls.append(1), real_gemm(*a, **k))[1]
+    try:
+        with torch.no_grad():                         # ordinary Parameters (requires_grad = True): the grad MODE decides (r2 ADVICE)
+            y_fused = gin(x, *meta)
+        assert len(calls) == 1 and gin.weights.requires_grad and y_fused.grad_fn is None
+        gin(x.clone().requires_grad_(True), *meta)     # training: the two-step form, A X is needed for dW
+        assert len(calls) == 1
+    finally:
+        T.forward_gemm = real_gemm
     assert T.last_kernel(*meta).split(" ")[0] in ("spmm_kernel", "spmm_lds_kernel", "spmm_lds_flat_kernel")
     y_two = gin(x.clone().requires_grad_(True), *meta)
     assert ((y_fused - y_two).abs() / (y_two.abs() + 10.0)).max().item() <= 1e-5
