@@ -562,7 +562,7 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
         if shape == "denser" and flat == "1":
             assert "columns beyond the cells' tiles moved to the cold remainder" in err and " 0 columns beyond" not in err
             # layouts with LDS to spare multiply the remainder inside the kernel, the others leave it to spmm_cold_planar_kernel
-            inside = D != 41                   # (the name follows the first pass: 1-2 planes x 4 windows and 2 planes x 8 windows have the room, 3 planes do not)
+            inside = True                      # (every layout these widths use has the room: a 3-plane remainder goes as 8-window chunks)
             assert kernel == ("spmm_lds_flat_kernel" if inside else "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)"), kernel
     assert out["0"][1].startswith("spmm_lds_kernel")
     assert torch.equal(Y, again)

@@ -20,7 +20,7 @@ def regs(tok):
     return out
 
 def audit(path, filt=""):
-    kernel, in_asm, vm, lgkm, bad = None, False, {}, {}, 0
+    kernel, in_asm, vm, lgkm, bad, skip_to = None, False, {}, {}, 0, None
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         m = re.match(r"^(_Z\w+):", s)
@@ -30,8 +30,15 @@ def audit(path, filt=""):
         # branches around every step) are not straight-line code: the approximation below does not apply, and they never run in the
         # product path
         if re.match(r"_Z20spmm_lds_flat_kernelILi\dELi\dELi\dELb1E", kernel): continue
-        if s.startswith(";;#ASMSTART"): in_asm = True; continue
-        if s.startswith(";;#ASMEND"): in_asm = False; continue
+        if s.startswith(";;#ASMSTART"): in_asm = True; skip_to = None; continue
+        if s.startswith(";;#ASMEND"): in_asm = False; skip_to = None; continue
+        # an asm statement with its own branch (lds_flat_step_if: "s_cbranch 1f ... s_branch 2f / 1: wait for everything / 2:"): the
+        # path that ISSUES loads is the one to follow - the other leaves nothing in flight - so what lies behind the unconditional
+        # s_branch is skipped up to its target label
+        if in_asm and skip_to is not None:
+            if re.match(r"^%s:" % re.escape(skip_to), s) or (skip_to[-1:] in "fb" and re.match(r"^%s:" % re.escape(skip_to[:-1]), s)): skip_to = None
+            continue
+        if in_asm and s.split()[0] == "s_branch": skip_to = s.split()[1]; continue
         if not s or s.startswith((";", ".")): continue
         op = s.split()[0]
         if op == "s_endpgm": kernel = None; continue
