@@ -67,6 +67,7 @@ def parse():
                    help="N > 1: all-gather X inside every step (always: the sharded-GCN step - the SpMM input is the previous layer's "
                         "row-sharded output, so a step without the gather is not the workload), replicate X and time the local SpMM "
                         "only (never), or exchange only when the global feature matrix does not fit one GPU (auto)")
+    p.add_argument("--all-generators", action="store_true", help="also the r02 graph variants (SBM with hubs, under random ids, relabelled)")
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
 
@@ -437,8 +438,11 @@ def single_gpu(args):
     if not args.no_extra and args.scale == 1.0:
         TCGNN.clear_plan_cache()
         every = ("spmm", "spmm_val", "sddmm", "agnn")
-        for shape, gen, d, ops in ((args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")),
-                                   (args.shape, "sbm_hubs", D, every), (args.shape, "sbm_shuffled", D, every), (args.shape, "sbm_shuffled+reorder", D, every + ("gcn_epoch", "agnn_epoch")),
+        # (the three generators SURVEY.md 8d names, plus the community graph calibrated to real Reddit's TC-block count -
+        #  tcgnn_graph.SBM_REDDIT_P_IN; the hub / shuffled / relabelled variants of r02 are behind --all-generators)
+        more = ((args.shape, "sbm_hubs", D, every), (args.shape, "sbm_shuffled", D, every), (args.shape, "sbm_shuffled+reorder", D, every + ("gcn_epoch", "agnn_epoch"))) if args.all_generators else ()
+        for shape, gen, d, ops in ((args.shape, "sbm_reddit", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")),
+                                   (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")), *more,
                                    ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
                                    ("ogbn-products", "sbm", 128, every),
                                    ("ogbn-products", "rmat", 128, every)):
@@ -591,6 +595,14 @@ def multi_gpu(args):
     except Exception as exc:   # an extra: must never take the headline down
         if rank == 0:
             print("fp16-exchange leg failed: %s" % str(exc)[:300], file=sys.stderr)
+    # ---- the exchange overlapped with the own-block product (RowShard.spmm_overlapped: the gather on a side stream)
+    t_overlap = float("nan")
+    try:
+        wo = lambda: shard.spmm_overlapped(x_local)
+        t_overlap = sync_time(wo, max(3, args.steps // 5), 2, barrier) * args.steps / max(3, args.steps // 5)
+    except Exception as exc:   # an extra: must never take the headline down
+        if rank == 0:
+            print("overlapped-exchange leg failed: %s" % str(exc)[:300], file=sys.stderr)
     # ---- one sharded GCN training epoch (2 layers, hidden D, main_tcgnn.py:146-181 on the shard): X W locally, all-gather +
     #      local SpMM forward and backward in both layers, one all-reduce of the weight gradients
     gcn_ms = float("nan")
@@ -606,7 +618,7 @@ def multi_gpu(args):
     except Exception as exc:   # the extra leg must never take the headline down
         if rank == 0:
             print("sharded GCN leg failed: %s" % str(exc)[:300], file=sys.stderr)
-    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16, t_overlap], dtype=torch.float64, device=dev)
     mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     out = None
@@ -631,7 +643,11 @@ def multi_gpu(args):
                       "exchange_fraction_if_exchanged": round(max(0.0, 1.0 - t_local / t_x), 4),
                       "gathered_X_bytes": int(shard.layout.num_cols) * D * 4,
                       "gcn_ms_per_epoch_sharded": None if np.isnan(float(mx[5])) else round(float(mx[5]), 3),
-                      "ms_per_step_with_fp16_exchange": None if np.isnan(float(mx[6])) else round(float(mx[6]) * 1e3 / args.steps, 4)},
+                      "ms_per_step_with_fp16_exchange": None if np.isnan(float(mx[6])) else round(float(mx[6]) * 1e3 / args.steps, 4),
+                      # the gather on a side stream under the product over the rank's own column block (RowShard.spmm_overlapped)
+                      "ms_per_step_with_overlapped_exchange": None if np.isnan(float(mx[7])) else round(float(mx[7]) * 1e3 / args.steps, 4),
+                      "exchange_fraction_if_overlapped": None if np.isnan(float(mx[7])) else round(max(0.0, 1.0 - t_local / float(mx[7])), 4),
+                      "own_block_edge_fraction": round(float(getattr(shard, "_own_frac", float("nan"))), 4)},
         }
     dist.barrier()
     dist.destroy_process_group()

@@ -249,6 +249,7 @@ class RowShard:
         self.rows = self.layout.rows[self.rank]
         self.local_row_pointers, self.local_column_index = lrp, lcol
         factory = ops_factory or HipShardOps
+        self._factory = factory
         self.ops = factory(lrp, lcol, self.layout, self.rank, self.device)
         self._gbuf = {}
 
@@ -268,6 +269,66 @@ class RowShard:
             return send
         all_gather_rows(recv, send, self.group)
         return recv
+
+    # ---- the exchange overlapped with the multiply ("report the exchange fraction and minimise it")
+    # A rank's columns split into its OWN block - whose X rows it already holds - and the rest: A_local = [A_own | A_rest].  The
+    # all-gather is issued on a side stream, A_own @ x_local runs meanwhile on the main one, and A_rest @ gathered follows when the
+    # blocks have landed; the two products are added.  Same operand rounding as the one-plan form (a 10-bit mantissa does not
+    # depend on the per-matrix power-of-two scale), another summation order: equal to `spmm` within accumulation noise, not bit
+    # for bit.  What it can hide is min(own-block multiply, gather): 1/world of the edges on a uniform graph, far more on a
+    # partitioned one (90 % of a METIS-style partition's edges are local).
+    def _split_ops(self):
+        if getattr(self, "_own", None) is None:
+            H, r = self.layout.H, self.rank
+            lrp, lcol = self.local_row_pointers.astype(np.int64), self.local_column_index.astype(np.int64)
+            own = (lcol >= r * H) & (lcol < (r + 1) * H)
+            erow = np.repeat(np.arange(len(lrp) - 1), np.diff(lrp))
+
+            def sub(mask, cols):
+                cnt = np.bincount(erow[mask], minlength=len(lrp) - 1)
+                rp = np.zeros(len(lrp), np.int32); rp[1:] = np.cumsum(cnt)
+                return rp, np.ascontiguousarray(cols.astype(np.int32))
+
+            own_layout = ShardLayout([0, H])          # the own block as a one-rank world: H feature rows, row_off 0
+            own_layout.H, own_layout.num_cols = H, H
+            factory = self._factory
+            self._own = factory(*sub(own, lcol[own] - r * H), own_layout, 0, self.device)
+            self._rest = factory(*sub(~own, lcol[~own]), self.layout, self.rank, self.device)
+            self._own_frac = float(own.mean()) if len(lcol) else 0.0
+        return self._own, self._rest
+
+    def spmm_overlapped(self, x_local):
+        """Y_local = A_local @ all_gather(X) with the gather on a side stream under the own-block product (see above)."""
+        own, rest = self._split_ops()
+        D, H = x_local.shape[1], self.layout.H
+        key = (D, x_local.dtype)
+        buf = self._gbuf.get(key)
+        if buf is None:
+            buf = (torch.zeros(H, D, dtype=x_local.dtype, device=x_local.device),
+                   torch.empty(self.world * H, D, dtype=x_local.dtype, device=x_local.device))
+            self._gbuf[key] = buf
+        send, recv = buf
+        send[: self.rows].copy_(x_local)
+        if not x_local.is_cuda:                      # (CPU stand-in of the tests: no streams)
+            if self.world > 1 or self.always_collective:
+                all_gather_rows(recv, send, self.group)
+            else:
+                recv = send
+            return own.spmm(send) + rest.spmm(recv)
+        main = torch.cuda.current_stream(x_local.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=x_local.device)
+        side = self._side
+        side.wait_stream(main)                       # `send` is ready; `recv`'s previous readers are done
+        with torch.cuda.stream(side):
+            if self.world > 1 or self.always_collective:
+                all_gather_rows(recv, send, self.group)
+            else:
+                recv[:H].copy_(send)
+        y = own.spmm(send)                           # ... while the blocks travel
+        main.wait_stream(side)
+        recv.record_stream(main)
+        return y.add_(rest.spmm(recv))
 
     def place_replicated(self, x_global):
         """No exchange: scatter a replicated [N, D] matrix into the gathered numbering (graphs

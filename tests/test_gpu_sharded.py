@@ -71,6 +71,8 @@ def _worker(rank, world, port, out_dir):
                         ok[tag + "fp16 wire == fp32 wire (mode %d)" % mode] = bool(torch.equal(a, b))
                 finally:
                     c.lib.tcgnn_set_spmm_mode(0)
+                Yo = shard.spmm_overlapped(x_local)                      # gather on a side stream under the own-block product
+                ok[tag + "overlapped exchange"] = bool(((Yo - Yl).abs() / scale).max().item() <= TIGHT)
                 Yv = shard.spmm_val(x_local, torch.from_numpy(att[e0:e1]).to(dev))
                 Yvfull = TCGNN.forward_AGNN(tX, meta[0], meta[1], torch.from_numpy(att).to(dev).view(1, -1), *meta[2:])[0]
                 _, absYv = O.spmm_f64(X, rp, col, att)
@@ -243,6 +245,8 @@ def _rccl_worker(rank, world, port, out_dir):
                 finally:
                     c.lib.tcgnn_set_spmm_mode(0)
             ok["D=%d sddmm" % D] = bool(torch.equal(plain.sddmm(X), coll.sddmm(X)))
+            a = plain.spmm(X)
+            ok["D=%d overlapped exchange (side-stream all-gather under RCCL)" % D] = bool(((coll.spmm_overlapped(X) - a).abs().max() <= 1e-4 * (a.abs().max() + 1.0)).item())
         # one whole training step with the gradient / loss all-reduces issued
         in_dim, hidden, classes = 20, 16, 5
         Xf = torch.randn(n, in_dim, device=dev) * 0.1
@@ -297,3 +301,4 @@ def test_bench_gpus_n_starts_its_own_ranks_and_prints_one_json_line_last():
     assert ex["exchange_in_timed_step"] is True
     assert ex["ms_per_step_with_exchange"] > 0 and ex["ms_per_step_with_fp16_exchange"] is not None
     assert ex["gcn_ms_per_epoch_sharded"] is not None
+    assert ex["ms_per_step_with_overlapped_exchange"] is not None and 0.0 <= ex["exchange_fraction_if_overlapped"] < 1.0

@@ -89,6 +89,8 @@ def _worker(rank, world, port, out_dir):
         ok["spmm_val"] = np.allclose(shard.spmm_val(x_local, torch.from_numpy(att[e0:e1])).numpy(), Yv[b0:b1], atol=1e-5)
         ef = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_NONE)
         ok["sddmm"] = np.allclose(shard.sddmm(x_local).numpy(), ef[e0:e1], atol=1e-4)
+        # the exchange overlapped with the own-block product: A_local = [A_own | A_rest], same result up to summation order
+        ok["overlapped"] = np.allclose(shard.spmm_overlapped(x_local).numpy(), Yfull[b0:b1], atol=1e-5) and 0.0 < shard._own_frac < 1.0
         # replicated placement (no exchange) gives the same gathered matrix as the collective
         ok["replicated"] = torch.equal(shard.place_replicated(torch.from_numpy(X)), shard.gather(x_local))
         # local-only construction (each rank materialises just its rows)

@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tc-gnn_atc23_amd"))
-TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
 QUICK = "--quick" in sys.argv
 ALLGEN = "--all-generators" in sys.argv
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + TAG)
@@ -65,7 +65,7 @@ def pmc_workload(shape, gen, D):
         for f in find(d, "*counter_collection*.csv"):
             for r in csv.DictReader(open(f)):
                 k = r.get("Kernel_Name", "")
-                if any(s in k for s in KERNELS) and "csr_kernel" not in k:
+                if any(s in k for s in KERNELS) and "csr_kernel" not in k and "fallback" not in k:
                     per_kernel[k.split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
         try:
             meta = [l for l in open(log) if l.startswith("E=")][-1].strip()
@@ -112,7 +112,7 @@ def main():
     rows = []
     work = [("reddit", "uniform", 64)] if QUICK else [("reddit", "uniform", 64), ("ogbn-products", "uniform", 128)]
     if ALLGEN:
-        work += [("reddit", "sbm", 64), ("reddit", "rmat", 64), ("reddit", "sbm_hubs", 64), ("reddit", "sbm_shuffled", 64), ("reddit", "sbm_shuffled+reorder", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]
+        work += [("reddit", "sbm_reddit", 64), ("reddit", "sbm", 64), ("reddit", "rmat", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]   # (bench.py's default dataset list)
     for shape, gen, D in work:
         rows += pmc_workload(shape, gen, D)
     json.dump({"build_id": bid, "round": TAG, "how": __doc__.split("3. traffic.json:")[1].strip(), "rows": rows},
