@@ -34,8 +34,10 @@
  *     smaller ones lose mantissa bits and, 2^39 below the maximum, are flushed - an absolute error of at most max|X| * 2^-39
  *     per element.  A matrix (or edge-value array) that holds BOTH a magnitude >= 2^8 and a nonzero one more than 2^28 below
  *     its maximum is routed - by a test on the device, no read-back - to fp32 fallback kernels that keep fp32's exponent like
- *     the reference does (slow, correct for any magnitudes); everything else stays on the MFMA path, where the bound above is
- *     below 1e-9.  Images the CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
+ *     the reference does (slow, correct for any magnitudes); everything else stays on the MFMA path.  "Large" is where a sum
+ *     of such errors could leave the contract's 1e-3 max(1, |ref|): max|X| above 2^29 / (longest row of the graph) for the
+ *     binary SpMM (2^19 at Reddit's degrees), max|A| max|X| above 2^28 / (longest row) for the edge-valued one, max|X| above
+ *     2^((29 - log2(2 D)) / 2) for SDDMM and the fused AGNN pair (2^11 at D = 64).  Images the CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
  *     header bytes 4 .. 255 must be zero.
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
@@ -168,6 +170,14 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * (no staging pass; binary SpMM only).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
  * initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
+
+/* The range guard (see "Operand range" above).  tcgnn_set_range_guard(0) switches it off process-wide (every call stays on the
+ * MFMA path; default on, environment TCGNN_RANGE_GUARD).  tcgnn_range_mode reports which way the LAST staged call on this
+ * workspace went: *wide_x = 1 if its feature matrix took the fp32 fallback as a binary SpMM / SDDMM / fused AGNN operand,
+ * *wide_val (optional) = 1 if it did as an edge-valued SpMM.  Reads 32 bytes of the workspace header back: synchronises `stream`
+ * (a test / diagnosis aid, like tcgnn_plan_last_kernel - the hot path never reads anything back). */
+int tcgnn_set_range_guard(int32_t on);
+int tcgnn_range_mode(const void* d_workspace, void* stream, int32_t* wide_x, int32_t* wide_val);
 
 /* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While
  * enabled, tcgnn_spmm / tcgnn_spmm_val / tcgnn_sddmm bracket their main kernel (not the fp16

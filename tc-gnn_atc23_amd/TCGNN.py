@@ -171,6 +171,25 @@ def prepare(widths, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToR
             _c.check(_c.lib.tcgnn_plan_prepare(plan, d, _stream_handle(dev)), "tcgnn_plan_prepare")
 
 
+def range_mode(device=None):
+    """Not part of the reference API: which way the range guard sent the LAST call staged on this device's current stream -
+    (wide_x, wide_val): 1 = the fp32 fallback ran (a matrix with a wide dynamic range, include/tcgnn.h "Operand range"), 0 = the
+    MFMA path.  Reads the workspace header back (synchronises the stream): a test / diagnosis aid."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _workspaces.get((dev.index, _stream_handle(dev)))
+    if ws is None:
+        return (0, 0)
+    off = (-ws.data_ptr()) % 256
+    a, b = _c._i32(0), _c._i32(0)
+    _c.check(_c.lib.tcgnn_range_mode(ws.data_ptr() + off, _stream_handle(dev), _c.ctypes.byref(a), _c.ctypes.byref(b)), "tcgnn_range_mode")
+    return (a.value, b.value)
+
+
+def set_range_guard(on):
+    """Not part of the reference API: switch the range guard off (0) or on (1, the default)."""
+    _c.check(_c.lib.tcgnn_set_range_guard(1 if on else 0), "tcgnn_set_range_guard")
+
+
 def kernel_timing(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, max_calls=None):
     """Not part of the reference API.  kernel_timing(meta..., max_calls=K) arms HIP-event timing of
     the main kernel for the next K calls on this graph; kernel_timing(meta...) (no max_calls) waits

@@ -66,6 +66,7 @@ struct tcgnn_plan {
     int32_t row_off = 0;                 // X row holding A's row 0 (row-sharded SDDMM)
     int64_t E = 0, tc_blocks = 0, total_wb = 0, max_wb = 0;   // max_wb: wide blocks of the longest window
     int canonical = 0, waves = 1;
+    int32_t max_degree = 0;              // longest row of A (max_degree_kernel at creation): the range guard's thresholds follow it
     const int32_t *rowptr = nullptr, *col = nullptr, *bp = nullptr, *e2c = nullptr, *e2r = nullptr; // borrowed
     int64_t* d_wb_ptr = nullptr;  // [nw_eff + 1] first wide block of each window
     int32_t* d_order = nullptr;   // [nw_eff] window ids, heaviest first
@@ -160,11 +161,26 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t
 // every other matrix the fallback returns at once.  The decision is made on the device from the staging pass's header words -
 // word k: bits of max |.| (k = 0: X, 1: edge values), word k + 2: 0x7f800000 - bits of the smallest nonzero |.| (0: none seen) -
 // so no call synchronises or reads anything back.
-__device__ __forceinline__ bool range_is_wide(const uint32_t* hdr, int k) {
+// hdr[k + 4]: the biased exponent from which a maximum counts as "large" for THIS call - written with the range words by the staging
+// pass (absmax_kernel), computed on the host from what the error can add up to (guard_exp_*): an operator and a graph whose sums
+// are short tolerate larger magnitudes.  0 (an image the caller staged): never wide.
+__device__ __forceinline__ bool range_spread(const uint32_t* hdr, int k, int& emax) {
     const uint32_t mx = hdr[k], mi = hdr[k + 2];
+    emax = (int)(mx >> 23);
     if (mi == 0u || mx == 0u || mx >= 0x7f800000u) return false;
-    const int emax = (int)(mx >> 23), emin = (int)((0x7f800000u - mi) >> 23);
-    return emax >= 127 + 8 && emax - emin > 28;
+    return emax - (int)((0x7f800000u - mi) >> 23) > 28;
+}
+__device__ __forceinline__ bool range_is_wide(const uint32_t* hdr, int k) {   // k = 0: the feature matrix alone
+    int emax;
+    const uint32_t thr = hdr[k + 4];
+    return range_spread(hdr, k, emax) && thr != 0u && emax >= (int)thr;
+}
+// edge-valued SpMM: the error is bilinear - 2 deg max|A| max|X| 2^-39 - so the PRODUCT of the two maxima is what counts as large
+__device__ __forceinline__ bool range_is_wide_val(const uint32_t* hdr) {
+    int ex, ea;
+    const bool sx = range_spread(hdr, 0, ex), sa = range_spread(hdr, 1, ea);
+    const uint32_t thr = hdr[5];
+    return (sx || sa) && thr != 0u && hdr[0] != 0u && hdr[1] != 0u && (ex - 127) + (ea - 127) >= (int)thr - 127;
 }
 
 // Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
@@ -237,6 +253,21 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
 // 2 reach / num_cols (1/8 at reach = num_cols / 16), a graph whose communities are numbered consecutively nearly all of them.
 // Decides between the per-window walk in XCD-contiguous order (co-resident workgroups share their gathered rows in L2) and the
 // range-blocked walk (which picks its windows strided over the whole graph).
+// longest row of the CSR (grid-stride; one atomic per workgroup)
+__global__ __launch_bounds__(256) void max_degree_kernel(const int32_t* __restrict__ rowptr, int32_t N, uint32_t* out) {
+    uint32_t m = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t d = rowptr[r + 1] - rowptr[r];
+        m = max(m, d > 0 ? (uint32_t)d : 0u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { m = max(max(wm[0], wm[1]), max(wm[2], wm[3])); if (m) atomicMax(out, m); }
+}
+
 __global__ __launch_bounds__(256) void locality_kernel(const int64_t* __restrict__ wb_ptr, const int32_t* __restrict__ cols, int32_t nw, int32_t Nc,
                                                        int32_t row_off, int32_t reach, unsigned long long* __restrict__ out) {
     const int w = blockIdx.x;
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
 // (out_lo: where the smallest nonzero magnitude is recorded for the range guard, nullptr: not wanted - images a caller stages
 //  itself, tcgnn_stage_absmax, carry no such word and are never "wide")
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, int64_t n,
-                                                     uint32_t* out, uint32_t* out_lo) {
+                                                     uint32_t* out, uint32_t* out_lo, uint32_t guard_exp) {
     uint32_t m = 0, lo = 0;   // lo: 0x7f800000 - bits of the smallest nonzero finite magnitude (larger = smaller; 0 = none): range_is_wide
     auto see = [&](float f) {
         const uint32_t b = __float_as_uint(f) & 0x7fffffffu;
@@ -334,11 +365,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
         lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
         if (lo && out_lo) atomicMax(out_lo, lo);
+        if (out_lo && blockIdx.x == 0) out_lo[2] = guard_exp;   // (word k + 4: from which exponent this call's maximum counts as large)
     }
 }
 
 // absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
-__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo) {
+__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_exp) {
     uint32_t m = 0, lo = 0;
     auto see = [&](float f, float gt) {
         const uint32_t b = gt > 0.0f ? __float_as_uint(f) & 0x7fffffffu : 0u;
@@ -369,6 +401,7 @@ __global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restri
         lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
         if (lo && out_lo) atomicMax(out_lo, lo);
+        if (out_lo && blockIdx.x == 0) out_lo[2] = guard_exp;   // (word k + 4: from which exponent this call's maximum counts as large)
     }
 }
 
@@ -743,7 +776,7 @@ struct TileWalker {
 // spent 24 v_accvgpr_* moves per tile shuffling them)
 template <int NT, int WAVES, bool VAL>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(const SpmmArgs a) {
-    if (range_is_wide(a.hdr, 0) || (VAL && range_is_wide(a.hdr, 1))) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    if (VAL ? range_is_wide_val(a.hdr) : range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -889,7 +922,7 @@ __global__ void bucket_ptr_kernel(const int64_t* __restrict__ wb_ptr, const int3
 
 template <int NT, int MAXW, bool VAL>
 __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(const SpmmBlockedArgs b) {
-    if (range_is_wide(b.base.hdr, 0) || (VAL && range_is_wide(b.base.hdr, 1))) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    if (VAL ? range_is_wide_val(b.base.hdr) : range_is_wide(b.base.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SpmmArgs& a = b.base;
     const int lane = threadIdx.x & 63;
@@ -1651,9 +1684,12 @@ struct SpmmSmallArgs {
     const float* gate;   // optional: operand element (r, c) counts only where gate[r, c] > 0 (ReLU backward mask)
     float* y;
     int32_t N, Nc, D, relu;
+    const uint32_t* guard;   // nullptr: the kernel of small graphs.  Else the header of a staged image: this launch is the range guard's
+                             // fallback behind an fp16-path kernel and returns at once unless that matrix is "wide" (range_is_wide)
 };
 typedef float floatx4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
+    if (a.guard && !range_is_wide(a.guard, 0)) return;
     const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
     const int w = blockIdx.x;
     const int coloff = (int)blockIdx.y * 64;
@@ -1739,7 +1775,7 @@ __global__ __launch_bounds__(256) void spmm_wide_fallback_kernel(const uint32_t*
                                                                  const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ wscale,
                                                                  const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int32_t N, int32_t D,
                                                                  int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe) {
-    if (!(range_is_wide(hdr, 0) || (use_val_word && range_is_wide(hdr, 1)))) return;
+    if (!(use_val_word ? range_is_wide_val(hdr) : range_is_wide(hdr, 0))) return;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
@@ -1964,13 +2000,28 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
     return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
 }
 
+// ---- range guard thresholds (range_is_wide): the biased exponent from which a call's largest magnitude counts as "large".  What an
+// element below max 2^-28 loses is at most max 2^-39 in absolute terms; a sum of deg such terms must stay inside the contract's
+// 1e-3 max(1, |ref|) whatever the result is, i.e. below 2^-10:
+//   binary SpMM        deg max 2^-39 <= 2^-10               -> max <= 2^29 / deg
+//   edge-valued SpMM   2 deg max|A| max|X| 2^-39 <= 2^-10   -> max|A| max|X| <= 2^28 / deg      (the product is tested)
+//   SDDMM / fused AGNN 2 D max^2 2^-39 <= 2^-10             -> max <= 2^((29 - log2(2 D)) / 2)
+// with deg = the longest row of the graph (plan->max_degree).  Uniform Reddit shape (deg <= ~600): 2^19 - a GCN's unscaled
+// activations stay below; a 100 k-degree hub lowers it to 2^12.  tcgnn_set_range_guard(0) switches the guard off (0 = never wide).
+static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 1; }();
+static uint32_t guard_bias(double e) { const int k = (int)std::floor(e); return g_range_guard ? (uint32_t)(127 + std::max(1, std::min(k, 100))) : 0u; }
+static uint32_t guard_exp_spmm(const tcgnn_plan* p) { return guard_bias(29.0 - std::log2((double)std::max(p->max_degree, 1))); }
+static uint32_t guard_exp_val(const tcgnn_plan* p) { return guard_bias(28.0 - std::log2((double)std::max(p->max_degree, 1))); }
+static uint32_t guard_exp_sddmm(int D) { return guard_bias((29.0 - std::log2(2.0 * std::max(D, 1))) / 2.0); }
+
 // ldx > 0: X (and the gate) is a column block of a wider row-major matrix with that row stride; the scale words in the
 // header were then computed over the WHOLE matrix by the caller (block_of_wider = true: no memset, no absmax pass here), so
 // every block is rounded exactly as the undivided call would round it.
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
                           const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr,
-                          int64_t ldx = 0, bool block_of_wider = false, const uint32_t* hdr_from = nullptr) {
+                          int64_t ldx = 0, bool block_of_wider = false, const uint32_t* hdr_from = nullptr, uint32_t guard_x = 0xffffffffu) {
+    if (guard_x == 0xffffffffu) guard_x = guard_exp_spmm(plan);   // (the binary SpMM's threshold unless the caller's operator has its own)
     // hdr_from: the scale words of an image of the same matrix staged a moment ago (the planar one of a plan with a cold remainder):
     // copied instead of recomputed, so both images are rounded with the same scale without a second pass over X
     const size_t need = workspace_bytes_for(plan->Nc, D);
@@ -1980,17 +2031,17 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     _Float16* x16 = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + kHdrBytes);
     const int dpad = round_up(D, 16);
     const int pitch = x16_pitch(dpad);
-    if (hdr_from) { HIP_TRY(hipMemcpyAsync(hdr, hdr_from, 16, hipMemcpyDeviceToDevice, stream)); block_of_wider = true; }
-    else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 16, stream));
+    if (hdr_from) { HIP_TRY(hipMemcpyAsync(hdr, hdr_from, 32, hipMemcpyDeviceToDevice, stream)); block_of_wider = true; }
+    else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 32, stream));
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2, guard_x);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2, guard_x);
     }
     if (d_val && plan->E > 0 && !block_of_wider) {
         const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3, guard_exp_val(plan));
     }
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
@@ -2691,7 +2742,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
     if (!d_val && !d_staged && !d_W && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
-        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu};
+        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, nullptr};
         KernelTimer timer(plan, stream, "spmm_small_kernel");
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
         HIP_TRY(hipGetLastError());
@@ -2760,14 +2811,14 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
             return fail(TCGNN_ERR_WORKSPACE, "workspace: need %zu bytes 256-aligned, got %zu at %p", need, ws_bytes, ws);
         uint32_t* whdr = static_cast<uint32_t*>(ws);
-        HIP_TRY(hipMemsetAsync(whdr, 0, 16, stream));
+        HIP_TRY(hipMemsetAsync(whdr, 0, 32, stream));
         const int64_t nx = (int64_t)plan->Nc * D;
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2, guard_exp_spmm(plan));
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2, guard_exp_spmm(plan));
         if (d_val && plan->E > 0) {
             const int g2 = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3);
+            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3, guard_exp_val(plan));
         }
         HIP_TRY(hipGetLastError());
         for (int c0 = 0; c0 < D; c0 += kMaxGatherBlockDims) {
@@ -2793,6 +2844,10 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         if (d_staged) return TCGNN_OK;
         const unsigned grid = (unsigned)((plan->N + 3) / 4);
         if (d_W) hipLaunchKernelGGL(spmm_gemm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_W, d_Y, plan->N, D, D_out, relu);
+        else if (!d_val && ld == D) {   // binary A, whole rows: the fp32-MFMA walk small graphs take anyway (10-bit operands, fp32's exponent)
+            const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, hdr};
+            hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
+        }
         else hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, d_val ? 1 : 0, plan->rowptr, plan->col, d_val, (const float*)nullptr, d_X, d_gate, d_Y,
                                 plan->N, D, (int64_t)ld, (int64_t)ld, relu, (!d_val && !plan->canonical) ? 1 : 0);
         HIP_TRY(hipGetLastError());
@@ -2914,7 +2969,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     if (!bwd) HIP_TRY(hipMemsetAsync(d_absmax, 0, sizeof(uint32_t), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, guard_exp_sddmm(D));
     if (rc) return rc;
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D));
     if (plan->nw_eff == 0) {
@@ -3023,9 +3078,20 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     std::vector<int32_t> bp((size_t)std::max(nw, 1));
     auto bail = [&](int rc) { tcgnn_plan_destroy(p); return rc; };
     if (nw > 0) {
-        hipError_t e = hipMemcpyAsync(bp.data(), d_blockPartition, (size_t)nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+        uint32_t* d_maxdeg = nullptr;   // the longest row: what the range guard's thresholds follow (guard_exp_*)
+        uint32_t h_maxdeg = 0;
+        hipError_t e = hipMalloc(&d_maxdeg, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_maxdeg, 0, sizeof(uint32_t), stream);
+        if (e == hipSuccess && num_nodes > 0) {
+            hipLaunchKernelGGL(max_degree_kernel, dim3((unsigned)std::min<int64_t>(1024, ((int64_t)num_nodes + 255) / 256)), dim3(256), 0, stream, d_nodePointer, num_nodes, d_maxdeg);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_maxdeg, d_maxdeg, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bp.data(), d_blockPartition, (size_t)nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_maxdeg);
         if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "read blockPartition: %s", hipGetErrorString(e)));
+        p->max_degree = (int32_t)std::min<uint32_t>(h_maxdeg, 0x7fffffffu);
     }
     std::vector<int64_t> wb_ptr((size_t)nw + 1, 0);
     for (int w = 0; w < nw; ++w) {
@@ -3208,6 +3274,29 @@ int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream_v) {
     return TCGNN_OK;
 }
 
+int tcgnn_set_range_guard(int32_t on) {
+    g_range_guard = on ? 1 : 0;
+    return TCGNN_OK;
+}
+
+int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, int32_t* wide_val) {
+    if (!d_workspace || !wide_x) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_range_mode: null argument");
+    uint32_t h[8];
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipMemcpyAsync(h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    auto spread = [&](int k, int& emax) {
+        emax = (int)(h[k] >> 23);
+        if (h[k + 2] == 0u || h[k] == 0u || h[k] >= 0x7f800000u) return false;
+        return emax - (int)((0x7f800000u - h[k + 2]) >> 23) > 28;
+    };
+    int ex = 0, ea = 0;
+    const bool sx = spread(0, ex), sa = spread(1, ea);
+    *wide_x = (sx && h[4] != 0u && ex >= (int)h[4]) ? 1 : 0;
+    if (wide_val) *wide_val = ((sx || sa) && h[5] != 0u && h[0] != 0u && h[1] != 0u && (ex - 127) + (ea - 127) >= (int)h[5] - 127) ? 1 : 0;
+    return TCGNN_OK;
+}
+
 int tcgnn_set_spmm_mode(int32_t mode) {
     if (mode < 0 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked), 3 (LDS-resident ranges) or 4 (single-launch fp32 kernel)");
     g_spmm_mode = mode;
@@ -3290,7 +3379,7 @@ int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stre
     if (n < 0 || (n > 0 && !d_X) || !d_word) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_absmax: null argument");
     if (n == 0) return TCGNN_OK;
     const int grid = (int)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr, 0u);
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }
@@ -3332,7 +3421,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch);
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, guard_exp_sddmm(D));
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};
     const int ks = (dpad + 31) / 32;

@@ -48,6 +48,8 @@ SIGNATURES = {
     "tcgnn_plan_destroy": (ctypes.c_int, [_vp]),
     "tcgnn_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfo)]),
     "tcgnn_set_spmm_mode": (ctypes.c_int, [_i32]),
+    "tcgnn_set_range_guard": (ctypes.c_int, [_i32]),
+    "tcgnn_range_mode": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "tcgnn_plan_set_timing": (ctypes.c_int, [_vp, _i32]),
     "tcgnn_plan_last_kernel": (ctypes.c_char_p, [_vp]),
     "tcgnn_plan_read_timing": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), _i32, ctypes.POINTER(_i32)]),

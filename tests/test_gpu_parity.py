@@ -944,9 +944,12 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
         tX = torch.from_numpy(X).to(dev)
         tatt = torch.from_numpy(att).to(dev).view(1, -1)
         Y = T.forward(tX, *meta)[0].cpu().numpy()
+        assert T.range_mode()[0] == (1 if wide else 0)       # which way the guard sent it (tcgnn_range_mode)
         Yr = T.forward_fused(tX, *meta, relu=True)[0].cpu().numpy()
         Yv = T.forward_AGNN(tX, meta[0], meta[1], tatt, *meta[2:])[0].cpu().numpy()
+        assert T.range_mode()[1] == (1 if wide else 0)
         ef = T.forward_ef(tX, *meta)[0].cpu().numpy()
+        assert T.range_mode()[0] == (1 if wide else 0)
         ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); r64, a64 = O.spmm_f64(X, rp, col)
         refv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, av64 = O.spmm_f64(X, rp, col, att)
         refe = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, ae64 = O.sddmm_f64(X, rp, col)
@@ -983,6 +986,25 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
         scale_dw = float((ae64 * col).sum()) + 1.0
         assert abs(float(dw) - want_dw) <= 1e-5 * scale_dw, (float(dw), want_dw)
         close(G.cpu().numpy())
+    # large but HARMLESS: activations of an unscaled GCN (max ~ 3e4, specks 13 orders below): with rows of at most ~150 edges what
+    # the specks lose cannot add up to 1e-3 - the threshold follows the graph's longest row (2^29 / deg) - so the MFMA path stays
+    X = (rng.standard_normal((n, D)) * 1e4).astype(np.float32)
+    X[::5] *= 1e-13
+    tX = torch.from_numpy(X).to(dev)
+    Y = T.forward(tX, *meta)[0].cpu().numpy()
+    assert T.range_mode()[0] == 0 and T.last_kernel(*meta).startswith("spmm_")
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert (np.abs(Y - ref) / np.maximum(1.0, np.abs(ref))).max() <= TOL
+    # the switch: with the guard off the wide matrix of the first case stays on the MFMA path
+    X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32); X[1234] = 1e6
+    T.set_range_guard(False)
+    try:
+        T.forward(torch.from_numpy(X).to(dev), *meta)
+        assert T.range_mode()[0] == 0
+    finally:
+        T.set_range_guard(True)
+    T.forward(torch.from_numpy(X).to(dev), *meta)
+    assert T.range_mode()[0] == 1
     T.clear_plan_cache()
 
 
