@@ -32,12 +32,14 @@
  *   - Operand range.  The MFMA kernels read a power-of-two-scaled fp16 image of X (one scale per matrix and call): every
  *     element within 2^28 of the largest is rounded bit-for-bit like the reference's TF32 operand (TCGNN_kernel.cu:438-444),
  *     smaller ones lose mantissa bits and, 2^39 below the maximum, are flushed - an absolute error of at most max|X| * 2^-39
- *     per element.  A matrix (or edge-value array) that holds BOTH a magnitude >= 2^8 and a nonzero one more than 2^28 below
- *     its maximum is routed - by a test on the device, no read-back - to fp32 fallback kernels that keep fp32's exponent like
- *     the reference does (slow, correct for any magnitudes); everything else stays on the MFMA path.  "Large" is where a sum
- *     of such errors could leave the contract's 1e-3 max(1, |ref|): max|X| above 2^29 / (longest row of the graph) for the
- *     binary SpMM (2^19 at Reddit's degrees), max|A| max|X| above 2^28 / (longest row) for the edge-valued one, max|X| above
- *     2^((29 - log2(2 D)) / 2) for SDDMM and the fused AGNN pair (2^11 at D = 64).  Images the CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
+ *     per element.  A matrix (or edge-value array) whose largest magnitude is LARGE and which holds nonzero elements more than
+ *     2^28 below it is routed - by a test on the device, no read-back - to fp32 fallback kernels that keep fp32's exponent like
+ *     the reference does (slow, correct for any magnitudes); everything else stays on the MFMA path.  "Large" is where the
+ *     errors one result can collect - at most k = min(longest row of the graph, number of elements of the matrix that lose
+ *     bits) of them for an SpMM, min(2 D, that number) for SDDMM and the fused AGNN pair - could leave the contract's
+ *     1e-3 max(1, |ref|): max|X| >= 2^29 / k (binary SpMM), max|A| max|X| >= 2^28 / k (edge-valued), max|X|^2 >= 2^29 / k
+ *     (SDDMM, fused AGNN).  A training epoch's activations (one stray 1e-5 among 1e4's) stay on the MFMA path.  Images the
+ *     CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
  *     header bytes 4 .. 255 must be zero.
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,

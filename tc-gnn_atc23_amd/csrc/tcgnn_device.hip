@@ -161,27 +161,46 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t
 // every other matrix the fallback returns at once.  The decision is made on the device from the staging pass's header words -
 // word k: bits of max |.| (k = 0: X, 1: edge values), word k + 2: 0x7f800000 - bits of the smallest nonzero |.| (0: none seen) -
 // so no call synchronises or reads anything back.
-// hdr[k + 4]: the biased exponent from which a maximum counts as "large" for THIS call - written with the range words by the staging
-// pass (absmax_kernel), computed on the host from what the error can add up to (guard_exp_*): an operator and a graph whose sums
-// are short tolerate larger magnitudes.  0 (an image the caller staged): never wide.
+// How large is "large": what an element below max 2^-28 loses is at most max 2^-39 in absolute terms, and a result may collect at
+// most k such errors - k = min(cap, n_tiny), cap = the longest row of the graph (SpMM) or 2 D (SDDMM, fused AGNN: the terms of one
+// dot product), n_tiny = how many elements of the matrix lose bits at all (counted by the conversion pass: ONE stray 1e-5 in a
+// matrix of 1e4's - what a training epoch's activations look like, tools/probe_training_ranges.py - costs one error, not cap).
+// The sum must stay inside the contract's 1e-3 max(1, |ref|) whatever the result is, i.e. below 2^-10:
+//   binary SpMM        k max 2^-39 <= 2^-10                 -> wide iff     log2 max  >= 29 - log2 k
+//   SDDMM / fused AGNN k max^2 2^-39 <= 2^-10               -> wide iff 2 * log2 max  >= 29 - log2 k
+//   edge-valued SpMM   2 k max|A| max|X| 2^-39 <= 2^-10     -> wide iff log2 max|A| + log2 max|X| >= 28 - log2 k
+// Header words (written by the staging pass): 4 = cap for X (0: guard off / an image the caller staged: never wide), 5 = cap for
+// the edge values, 6 = n_tiny of X, 7 = the power of max in the bound (1 or 2).
 __device__ __forceinline__ bool range_spread(const uint32_t* hdr, int k, int& emax) {
     const uint32_t mx = hdr[k], mi = hdr[k + 2];
     emax = (int)(mx >> 23);
     if (mi == 0u || mx == 0u || mx >= 0x7f800000u) return false;
     return emax - (int)((0x7f800000u - mi) >> 23) > 28;
 }
-__device__ __forceinline__ bool range_is_wide(const uint32_t* hdr, int k) {   // k = 0: the feature matrix alone
+__device__ __forceinline__ int ceil_log2_u32(uint32_t k) { return k <= 1u ? 0 : 32 - __clz((int)(k - 1u)); }
+__device__ __forceinline__ bool range_is_wide(const uint32_t* hdr, int) {   // the feature matrix alone (binary SpMM, SDDMM, fused AGNN)
     int emax;
-    const uint32_t thr = hdr[k + 4];
-    return range_spread(hdr, k, emax) && thr != 0u && emax >= (int)thr;
+    const uint32_t cap = hdr[4], n = hdr[6];
+    if (!range_spread(hdr, 0, emax) || cap == 0u || n == 0u) return false;
+    return (int)hdr[7] * (emax - 127) >= 29 - ceil_log2_u32(n < cap ? n : cap);
 }
-// edge-valued SpMM: the error is bilinear - 2 deg max|A| max|X| 2^-39 - so the PRODUCT of the two maxima is what counts as large
 __device__ __forceinline__ bool range_is_wide_val(const uint32_t* hdr) {
     int ex, ea;
     const bool sx = range_spread(hdr, 0, ex), sa = range_spread(hdr, 1, ea);
-    const uint32_t thr = hdr[5];
-    return (sx || sa) && thr != 0u && hdr[0] != 0u && hdr[1] != 0u && (ex - 127) + (ea - 127) >= (int)thr - 127;
+    const uint32_t cap = hdr[5];
+    if (!(sx || sa) || cap == 0u || hdr[0] == 0u || hdr[1] == 0u) return false;
+    const uint32_t n = hdr[6], k = (sa || n >= cap) ? cap : (n ? n : 1u);   // (edge values that lose bits are not counted: the longest row bounds them)
+    return (ex - 127) + (ea - 127) >= 28 - ceil_log2_u32(k);
 }
+// conversion pass: this thread's count of elements that lose bits (nonzero, below fp16's normal range once scaled) -> hdr[6]
+__device__ __forceinline__ void count_tiny(uint32_t* cnt, uint32_t mine) {   // mine <= 15; lanes that left the kernel early count as 0
+    if (!cnt) return;
+    uint32_t total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) total += (uint32_t)__popcll(__ballot((mine >> b) & 1u)) << b;
+    if (total && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(cnt, total);
+}
+__device__ __forceinline__ uint32_t is_tiny(float scaled) { const float a = fabsf(scaled); return (a > 0.0f && a < 6.103515625e-5f) ? 1u : 0u; }
 
 // Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
 // wmma::__float_to_tf32 (cvt.rna.tf32.f32, TCGNN_kernel.cu:441-444) does.  The result has at most
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
 // (out_lo: where the smallest nonzero magnitude is recorded for the range guard, nullptr: not wanted - images a caller stages
 //  itself, tcgnn_stage_absmax, carry no such word and are never "wide")
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, int64_t n,
-                                                     uint32_t* out, uint32_t* out_lo, uint32_t guard_exp) {
+                                                     uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
     uint32_t m = 0, lo = 0;   // lo: 0x7f800000 - bits of the smallest nonzero finite magnitude (larger = smaller; 0 = none): range_is_wide
     auto see = [&](float f) {
         const uint32_t b = __float_as_uint(f) & 0x7fffffffu;
@@ -365,12 +384,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
         lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
         if (lo && out_lo) atomicMax(out_lo, lo);
-        if (out_lo && blockIdx.x == 0) out_lo[2] = guard_exp;   // (word k + 4: from which exponent this call's maximum counts as large)
+        if (out_lo && blockIdx.x == 0) { out_lo[2] = guard_cap; if (guard_pow) out_lo[5] = guard_pow; }   // (words k + 4 and, for X, 7: range_is_wide)
     }
 }
 
 // absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
-__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_exp) {
+__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
     uint32_t m = 0, lo = 0;
     auto see = [&](float f, float gt) {
         const uint32_t b = gt > 0.0f ? __float_as_uint(f) & 0x7fffffffu : 0u;
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restri
         lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
         if (m) atomicMax(out, m);
         if (lo && out_lo) atomicMax(out_lo, lo);
-        if (out_lo && blockIdx.x == 0) out_lo[2] = guard_exp;   // (word k + 4: from which exponent this call's maximum counts as large)
+        if (out_lo && blockIdx.x == 0) { out_lo[2] = guard_cap; if (guard_pow) out_lo[5] = guard_pow; }   // (words k + 4 and, for X, 7: range_is_wide)
     }
 }
 
@@ -411,7 +430,8 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
                                                       int32_t D, int32_t Dpad, int32_t pitch,
                                                       _Float16* __restrict__ X16,
-                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr, int64_t ldx = 0) {
+                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr, int64_t ldx = 0,
+                                                      uint32_t* __restrict__ tiny = nullptr) {
     if (ldx == 0) ldx = D;   // row stride of X (and G) in floats: > D when X is a column block of a wider matrix
     const int cpr = Dpad >> 3;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,6 +458,10 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
         }
     }
     *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
+    uint32_t nt = 0;   // elements that lose bits in the image (range guard): nonzero, below fp16's normal range
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nt += is_tiny((float)o[j]);
+    count_tiny(tiny, nt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2000,19 +2024,13 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
     return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
 }
 
-// ---- range guard thresholds (range_is_wide): the biased exponent from which a call's largest magnitude counts as "large".  What an
-// element below max 2^-28 loses is at most max 2^-39 in absolute terms; a sum of deg such terms must stay inside the contract's
-// 1e-3 max(1, |ref|) whatever the result is, i.e. below 2^-10:
-//   binary SpMM        deg max 2^-39 <= 2^-10               -> max <= 2^29 / deg
-//   edge-valued SpMM   2 deg max|A| max|X| 2^-39 <= 2^-10   -> max|A| max|X| <= 2^28 / deg      (the product is tested)
-//   SDDMM / fused AGNN 2 D max^2 2^-39 <= 2^-10             -> max <= 2^((29 - log2(2 D)) / 2)
-// with deg = the longest row of the graph (plan->max_degree).  Uniform Reddit shape (deg <= ~600): 2^19 - a GCN's unscaled
-// activations stay below; a 100 k-degree hub lowers it to 2^12.  tcgnn_set_range_guard(0) switches the guard off (0 = never wide).
+// ---- range guard parameters (range_is_wide): cap = how many lost-precision terms one result can collect at most - the longest row
+// of the graph (SpMM) or 2 D (SDDMM / fused AGNN) - and the power of max|X| in the error bound.  cap 0 = guard off
+// (tcgnn_set_range_guard(0), TCGNN_RANGE_GUARD=0).
 static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 1; }();
-static uint32_t guard_bias(double e) { const int k = (int)std::floor(e); return g_range_guard ? (uint32_t)(127 + std::max(1, std::min(k, 100))) : 0u; }
-static uint32_t guard_exp_spmm(const tcgnn_plan* p) { return guard_bias(29.0 - std::log2((double)std::max(p->max_degree, 1))); }
-static uint32_t guard_exp_val(const tcgnn_plan* p) { return guard_bias(28.0 - std::log2((double)std::max(p->max_degree, 1))); }
-static uint32_t guard_exp_sddmm(int D) { return guard_bias((29.0 - std::log2(2.0 * std::max(D, 1))) / 2.0); }
+struct Guard { uint32_t cap, pow; };
+static Guard guard_spmm(const tcgnn_plan* p) { return {g_range_guard ? (uint32_t)std::max(p->max_degree, 1) : 0u, 1u}; }
+static Guard guard_sddmm(int D) { return {g_range_guard ? (uint32_t)(2 * std::max(D, 1)) : 0u, 2u}; }
 
 // ldx > 0: X (and the gate) is a column block of a wider row-major matrix with that row stride; the scale words in the
 // header were then computed over the WHOLE matrix by the caller (block_of_wider = true: no memset, no absmax pass here), so
@@ -2020,8 +2038,8 @@ static uint32_t guard_exp_sddmm(int D) { return guard_bias((29.0 - std::log2(2.0
 static int stage_features(const tcgnn_plan* plan, const float* d_X, const float* d_val, int32_t D,
                           void* ws, size_t ws_bytes, hipStream_t stream, const uint32_t** hdr_out,
                           const _Float16** x16_out, int* dpad_out, int* pitch_out, bool planar = false, const float* d_gate = nullptr,
-                          int64_t ldx = 0, bool block_of_wider = false, const uint32_t* hdr_from = nullptr, uint32_t guard_x = 0xffffffffu) {
-    if (guard_x == 0xffffffffu) guard_x = guard_exp_spmm(plan);   // (the binary SpMM's threshold unless the caller's operator has its own)
+                          int64_t ldx = 0, bool block_of_wider = false, const uint32_t* hdr_from = nullptr, const Guard* guard = nullptr) {
+    const Guard gx = guard ? *guard : guard_spmm(plan);   // (the binary SpMM's bound unless the caller's operator has its own)
     // hdr_from: the scale words of an image of the same matrix staged a moment ago (the planar one of a plan with a cold remainder):
     // copied instead of recomputed, so both images are rounded with the same scale without a second pass over X
     const size_t need = workspace_bytes_for(plan->Nc, D);
@@ -2036,27 +2054,28 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2, guard_x);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2, guard_x);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2, gx.cap, gx.pow);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2, gx.cap, gx.pow);
     }
     if (d_val && plan->E > 0 && !block_of_wider) {
         const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3, guard_exp_val(plan));
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3, guard_spmm(plan).cap, 0u);
     }
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
+    uint32_t* const tiny = hdr_from ? nullptr : hdr + 6;   // (a second image of the same matrix: its elements are counted already)
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0);
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
         if (vec && D % 16 == 0 && (!d_gate || (reinterpret_cast<uintptr_t>(d_gate) & 15) == 0)) {
             const int64_t threads = ((int64_t)plan->Nc + 1) * (D / 4);
-            hipLaunchKernelGGL(convert_planar_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_X, plan->Nc, D, x16, hdr, d_gate);
-        } else if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
+            hipLaunchKernelGGL(convert_planar_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_X, plan->Nc, D, x16, hdr, d_gate, tiny);
+        } else if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
         else if ((size_t)D * 64 * sizeof(float) <= 48 * 1024)
             hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
-                               d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
-        else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate);
-    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx);
+                               d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
+        else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
+    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny);
+    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny);
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
     return TCGNN_OK;
@@ -2814,11 +2833,11 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipMemsetAsync(whdr, 0, 32, stream));
         const int64_t nx = (int64_t)plan->Nc * D;
         const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2, guard_exp_spmm(plan));
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2, guard_exp_spmm(plan));
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
         if (d_val && plan->E > 0) {
             const int g2 = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3, guard_exp_val(plan));
+            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3, guard_spmm(plan).cap, 0u);
         }
         HIP_TRY(hipGetLastError());
         for (int c0 = 0; c0 < D; c0 += kMaxGatherBlockDims) {
@@ -2969,7 +2988,8 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     if (!bwd) HIP_TRY(hipMemsetAsync(d_absmax, 0, sizeof(uint32_t), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, guard_exp_sddmm(D));
+    const Guard gsd = guard_sddmm(D);
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D));
     if (plan->nw_eff == 0) {
@@ -3078,7 +3098,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     std::vector<int32_t> bp((size_t)std::max(nw, 1));
     auto bail = [&](int rc) { tcgnn_plan_destroy(p); return rc; };
     if (nw > 0) {
-        uint32_t* d_maxdeg = nullptr;   // the longest row: what the range guard's thresholds follow (guard_exp_*)
+        uint32_t* d_maxdeg = nullptr;   // the longest row: what the range guard's bound follows (guard_spmm)
         uint32_t h_maxdeg = 0;
         hipError_t e = hipMalloc(&d_maxdeg, sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemsetAsync(d_maxdeg, 0, sizeof(uint32_t), stream);
@@ -3290,10 +3310,14 @@ int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, i
         if (h[k + 2] == 0u || h[k] == 0u || h[k] >= 0x7f800000u) return false;
         return emax - (int)((0x7f800000u - h[k + 2]) >> 23) > 28;
     };
+    auto clog2 = [](uint32_t k) { int c = 0; while (c < 32 && (1ull << c) < k) ++c; return c; };   // (the host mirror of range_is_wide / range_is_wide_val)
     int ex = 0, ea = 0;
     const bool sx = spread(0, ex), sa = spread(1, ea);
-    *wide_x = (sx && h[4] != 0u && ex >= (int)h[4]) ? 1 : 0;
-    if (wide_val) *wide_val = ((sx || sa) && h[5] != 0u && h[0] != 0u && h[1] != 0u && (ex - 127) + (ea - 127) >= (int)h[5] - 127) ? 1 : 0;
+    *wide_x = (sx && h[4] != 0u && h[6] != 0u && (int)h[7] * (ex - 127) >= 29 - clog2(std::min(h[4], h[6]))) ? 1 : 0;
+    if (wide_val) {
+        const uint32_t k = (sa || h[6] >= h[5]) ? h[5] : std::max(h[6], 1u);
+        *wide_val = ((sx || sa) && h[5] != 0u && h[0] != 0u && h[1] != 0u && (ex - 127) + (ea - 127) >= 28 - clog2(k)) ? 1 : 0;
+    }
     return TCGNN_OK;
 }
 
@@ -3379,7 +3403,7 @@ int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stre
     if (n < 0 || (n > 0 && !d_X) || !d_word) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_absmax: null argument");
     if (n == 0) return TCGNN_OK;
     const int grid = (int)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr, 0u, 0u);
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }
@@ -3421,7 +3445,8 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, guard_exp_sddmm(D));
+    const Guard gsd = guard_sddmm(D);
+    int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};
     const int ks = (dpad + 31) / 32;

@@ -986,15 +986,22 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
         scale_dw = float((ae64 * col).sum()) + 1.0
         assert abs(float(dw) - want_dw) <= 1e-5 * scale_dw, (float(dw), want_dw)
         close(G.cpu().numpy())
-    # large but HARMLESS: activations of an unscaled GCN (max ~ 3e4, specks 13 orders below): with rows of at most ~150 edges what
-    # the specks lose cannot add up to 1e-3 - the threshold follows the graph's longest row (2^29 / deg) - so the MFMA path stays
-    X = (rng.standard_normal((n, D)) * 1e4).astype(np.float32)
-    X[::5] *= 1e-13
+    # large but HARMLESS: what a training epoch's operands look like (tools/probe_training_ranges.py: max 2e4, ONE element 2^28.7
+    # below it) - one lost element is one error of max 2^-39, whatever the graph: the MFMA path stays, for every operator
+    X = (rng.standard_normal((n, D)) * 5e3).astype(np.float32)
+    X[np.abs(X) < 1.0] = 1.0                     # nothing small ...
+    X[77, 5] = 2e-5                              # ... but one speck
     tX = torch.from_numpy(X).to(dev)
     Y = T.forward(tX, *meta)[0].cpu().numpy()
     assert T.range_mode()[0] == 0 and T.last_kernel(*meta).startswith("spmm_")
     ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
     assert (np.abs(Y - ref) / np.maximum(1.0, np.abs(ref))).max() <= TOL
+    T.forward_ef(tX, *meta)
+    assert T.range_mode()[0] == 0
+    # ... while thousands of specks under a large maximum are not: 2^15 x 2^-39 x (a row's ~150 edges) is past the bar
+    X[::3] = 2e-5
+    T.forward(torch.from_numpy(X).to(dev), *meta)
+    assert T.range_mode()[0] == 1
     # the switch: with the guard off the wide matrix of the first case stays on the MFMA path
     X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32); X[1234] = 1e6
     T.set_range_guard(False)
