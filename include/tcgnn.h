@@ -173,12 +173,18 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
 
-/* The range guard (see "Operand range" above).  tcgnn_set_range_guard(0) switches it off process-wide (every call stays on the
- * MFMA path; default on, environment TCGNN_RANGE_GUARD).  tcgnn_range_mode reports which way the LAST staged call on this
+/* The range guard (see "Operand range" above), process-wide level (environment TCGNN_RANGE_GUARD sets the initial one):
+ *   0  off - every call stays on the MFMA path;
+ *   1  (default) the aggregation operators are guarded: tcgnn_spmm / _fused / _gemm and tcgnn_spmm_val, whose error bound is
+ *      LINEAR in max|X| - k max 2^-39 - and which ordinary training tensors never reach;
+ *   2  also tcgnn_sddmm and the fused AGNN pair, whose bound is QUADRATIC - min(2 D, lost elements) max|X|^2 2^-39: with the
+ *      reference's unscaled weights an AGNN epoch's activations (max ~3e4, one element 2^28 below) cross it now and then, and
+ *      such a call then costs ~25 ms in the fp32 CSR fallbacks instead of 2 ms.  At levels 0 and 1 those two operators answer to
+ *      that bound as documented.  tcgnn_range_mode reports which way the LAST staged call on this
  * workspace went: *wide_x = 1 if its feature matrix took the fp32 fallback as a binary SpMM / SDDMM / fused AGNN operand,
  * *wide_val (optional) = 1 if it did as an edge-valued SpMM.  Reads 32 bytes of the workspace header back: synchronises `stream`
  * (a test / diagnosis aid, like tcgnn_plan_last_kernel - the hot path never reads anything back). */
-int tcgnn_set_range_guard(int32_t on);
+int tcgnn_set_range_guard(int32_t level);
 int tcgnn_range_mode(const void* d_workspace, void* stream, int32_t* wide_x, int32_t* wide_val);
 
 /* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While

@@ -185,9 +185,10 @@ def range_mode(device=None):
     return (a.value, b.value)
 
 
-def set_range_guard(on):
-    """Not part of the reference API: switch the range guard off (0) or on (1, the default)."""
-    _c.check(_c.lib.tcgnn_set_range_guard(1 if on else 0), "tcgnn_set_range_guard")
+def set_range_guard(level):
+    """Not part of the reference API: the range guard's level - 0 off, 1 the SpMM operators (default), 2 every operator
+    (include/tcgnn.h: tcgnn_set_range_guard)."""
+    _c.check(_c.lib.tcgnn_set_range_guard(int(level)), "tcgnn_set_range_guard")
 
 
 def kernel_timing(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, max_calls=None):

@@ -923,6 +923,14 @@ def test_range_robustness_beyond_fp16(dev, T):
 
 
 def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
+    try:
+        _wide_range_body(dev, T)
+    finally:
+        T.set_range_guard(1)      # the default level, whatever happened
+        T.clear_plan_cache()
+
+
+def _wide_range_body(dev, T):
     """VERDICT r02 item 6 / SURVEY.md 7.3: ONE power-of-two scale per matrix loses the elements more than 2^28 below the largest
     (fp16 subnormals, then zero) where the reference's TF32 keeps fp32's exponent (TCGNN_kernel.cu:438-444).  O(1e-3) data with one
     1e6 row: rows that never touch the outlier must still come out to accumulation-order accuracy, which the fp16 image cannot
@@ -933,6 +941,7 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
     assert T.plan_info(*meta)["wide_blocks"] > 8192
     n, D = len(rp) - 1, 64
     rng = np.random.default_rng(11)
+    T.set_range_guard(2)                                      # every operator (the default level guards the SpMM operators only)
     att = rng.standard_normal(len(col)).astype(np.float32)
     for name, outlier, wide in (("outlier 1e6 over 1e-3 data", 1e6, True), ("1e-14 specks in O(1) data", None, False)):
         X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32)
@@ -1004,14 +1013,16 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
     assert T.range_mode()[0] == 1
     # the switch: with the guard off the wide matrix of the first case stays on the MFMA path
     X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32); X[1234] = 1e6
-    T.set_range_guard(False)
+    T.set_range_guard(0)
     try:
         T.forward(torch.from_numpy(X).to(dev), *meta)
         assert T.range_mode()[0] == 0
     finally:
-        T.set_range_guard(True)
+        T.set_range_guard(1)
     T.forward(torch.from_numpy(X).to(dev), *meta)
     assert T.range_mode()[0] == 1
+    T.forward_ef(torch.from_numpy(X).to(dev), *meta)          # level 1: SDDMM answers to its documented bound
+    assert T.range_mode()[0] == 0
     T.clear_plan_cache()
 
 

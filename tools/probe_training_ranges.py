@@ -24,8 +24,9 @@ def wrap(name, fn, idx=0):
         nz = x[x > 0]
         mx = float(x.max()); mn = float(nz.min()) if nz.numel() else 0.0
         tiny = int((nz < mx * 2.0 ** -28).sum())
-        seen.append((name, tuple(a[idx].shape), mx, mn, tiny, TCGNN.range_mode() if False else None))
-        return fn(*a, **k)
+        out = fn(*a, **k)
+        seen.append((name, tuple(a[idx].shape), mx, mn, tiny, TCGNN.range_mode()))
+        return out
     return f
 for name in ("forward", "forward_fused", "forward_gemm", "forward_AGNN", "forward_ef", "agnn_fused_forward", "agnn_fused_backward"):
     setattr(TCGNN, name, wrap(name, getattr(TCGNN, name)))
@@ -35,4 +36,4 @@ for model in ("gcn", "agnn"):
     H.time_training(model, meta, feats, labels, in_dim, 64, classes, 2, 1, seed=0, warmup=2, tune=False)
     print(model, gen)
     for s in seen[-8:]:
-        print("   %-20s %-16s max %.3e  min nonzero %.3e  (2^%.1f below)  tiny %d" % (s[0], s[1], s[2], s[3], (torch.log2(torch.tensor(s[2] / max(s[3], 1e-45)))).item(), s[4]))
+        print("   %-20s %-16s max %.3e  min nonzero %.3e  (2^%.1f below)  tiny %d  guard %s" % (s[0], s[1], s[2], s[3], (torch.log2(torch.tensor(s[2] / max(s[3], 1e-45)))).item(), s[4], s[5]))
