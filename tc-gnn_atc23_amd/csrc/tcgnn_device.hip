@@ -1977,6 +1977,7 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
 static int g_bucket_min_tiles = [] { const char* e = getenv("TCGNN_BUCKET_MIN_TILES"); return e ? atoi(e) : 2; }();   // tiles per (window, bucket) a bucket table needs
 static int g_lds_auto = [] { const char* e = getenv("TCGNN_LDS_AUTO"); return e ? atoi(e) : 1; }();
 static int g_lds_dbg = [] { const char* e = getenv("TCGNN_LDS_DBG"); return e ? atoi(e) : 0; }();
+static int g_lds_fill_quota = [] { const char* e = getenv("TCGNN_LDS_FILL_QUOTA"); return e ? atoi(e) : 1; }();   // A/B aid (tcgnn_lds_flat.inc)
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
@@ -2906,7 +2907,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (cs.flat_tpc) {
                 const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
-                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_wcold_ptr, cs.d_wcold};
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold};
                 HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
