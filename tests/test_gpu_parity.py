@@ -536,9 +536,10 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     rng = np.random.default_rng(D + 5)
     X = rng.standard_normal((n, D)).astype(np.float32)
-    (tX,) = to_dev(dev, X)
+    W = (rng.standard_normal((D, 24)) / D ** 0.5).astype(np.float32)
+    tX, tW = to_dev(dev, X, W)
     monkeypatch.setenv("TCGNN_VERBOSE", "1")
-    out = {}
+    out, gemm = {}, {}
     try:
         for f in (flat, "0"):
             monkeypatch.setenv("TCGNN_LDS_FLAT", f)
@@ -546,6 +547,8 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
             c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
             Y = T.forward(tX, *meta)[0]
             out[f] = (Y, T.last_kernel(*meta), T.forward_fused(tX, *meta, relu=True)[0], T.forward_fused(tX, *meta, gate=Y)[0], T.forward(tX, *meta)[0])
+            if D <= 64:    # the dense update in the epilogue (f3): the flat kernel multiplies its cold remainder itself, so it keeps the update
+                gemm[f] = (T.forward_gemm(tX, tW, *meta)[0], T.last_kernel(*meta), T.forward_gemm(tX, tW, *meta, relu=True)[0])
         c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
         Y1 = T.forward(tX, *meta)[0]
         Yg1 = T.forward_fused(tX, *meta, gate=out[flat][0])[0]
@@ -573,6 +576,15 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
     assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
     assert torch.equal(Yr, torch.relu(Y))
     assert np.abs(Yg.cpu().numpy() - Yg1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+    if gemm:
+        Z, zkernel, Zr = gemm[flat]
+        if kernel.startswith("spmm_lds_flat_kernel"): assert zkernel == "spmm_lds_flat_kernel", zkernel
+        want = Y.double().cpu().numpy() @ W.astype(np.float64)          # the update of the kernel's own aggregate, fp32 MFMA
+        scale = np.abs(absY).max() * np.abs(W).sum(0).max() + 1.0
+        assert np.abs(Z.cpu().numpy() - want).max() <= 1e-5 * scale, np.abs(Z.cpu().numpy() - want).max()
+        assert torch.equal(Zr, torch.relu(Z))
+        if gemm["0"][1].startswith("spmm_lds_kernel"):
+            assert np.abs(gemm["0"][0].cpu().numpy() - Z.cpu().numpy()).max() <= TIGHT * scale
 
 
 @pytest.mark.parametrize("D", [16, 48, 64, 96, 128])
