@@ -1,6 +1,6 @@
 // Micro-benchmark: how fast can one CU (16 wavefronts) take 48 KB ranges of an fp16 image into LDS -
 // (a) by LDS-DMA (global_load_lds_dwordx4), (b) through registers (global_load_dwordx4 + ds_write_b128) - with every CU at it at once.
-// Build: hipcc --offload-arch=gfx950 -O3 -o ingest ingest.hip ; run: ./ingest [MB of source]
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/ingest_bench tools/ingest_bench.hip ; run: tools/bin/ingest_bench [MB of source]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
