@@ -351,77 +351,66 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ r
 // ------------------------------------------------------------------------------------------
 // (out_lo: where the smallest nonzero magnitude is recorded for the range guard, nullptr: not wanted - images a caller stages
 //  itself, tcgnn_stage_absmax, carry no such word and are never "wide")
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p, int64_t n,
-                                                     uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
+// Both absmax kernels: kAbsmaxThreads threads per workgroup, four independent 16-byte loads in flight per thread (r03: one load per
+// trip of a grid-stride loop left 8 KB in flight per CU - 25 us for the 60 MB of a Reddit-shaped X, 2.4 TB/s), one atomic per
+// workgroup and word.
+constexpr int kAbsmaxThreads = 1024;
+// one workgroup per CU at most, and none without sixteen 16-byte loads per thread to do
+static inline int absmax_grid(int64_t n) { return (int)std::min<int64_t>(256, n / ((int64_t)kAbsmaxThreads * 64) + 1); }
+template <bool GATED>
+__device__ __forceinline__ void absmax_body(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo,
+                                            uint32_t guard_cap, uint32_t guard_pow) {
     uint32_t m = 0, lo = 0;   // lo: 0x7f800000 - bits of the smallest nonzero finite magnitude (larger = smaller; 0 = none): range_is_wide
-    auto see = [&](float f) {
-        const uint32_t b = __float_as_uint(f) & 0x7fffffffu;
+    auto see = [&](float f, float gt) {
+        const uint32_t b = (!GATED || gt > 0.0f) ? __float_as_uint(f) & 0x7fffffffu : 0u;
         m = max(m, b);
         lo = max(lo, (b - 1u < 0x7f7fffffu) ? 0x7f800000u - b : 0u);   // (b - 1 wraps for 0: zero, Inf and NaN do not count)
     };
+    auto see4 = [&](const float4& v, const float4& gt) { see(v.x, gt.x); see(v.y, gt.y); see(v.z, gt.z); see(v.w, gt.w); };
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    const uintptr_t both = reinterpret_cast<uintptr_t>(p) | (GATED ? reinterpret_cast<uintptr_t>(gate) : 0);
+    if ((both & 15) == 0) {   // (scalar loads: 85 us for 2 x 60 MB)
         const int64_t n4 = n >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (int64_t k = gid; k < n4; k += gsz) {
-            const float4 v = p4[k];
-            see(v.x); see(v.y); see(v.z); see(v.w);
+        const float4* g4 = reinterpret_cast<const float4*>(gate);
+        const float4 one = {1.f, 1.f, 1.f, 1.f};
+        int64_t k = gid;
+        for (; k + 3 * gsz < n4; k += 4 * gsz) {
+            const float4 v0 = p4[k], v1 = p4[k + gsz], v2 = p4[k + 2 * gsz], v3 = p4[k + 3 * gsz];
+            if constexpr (GATED) {
+                const float4 t0 = g4[k], t1 = g4[k + gsz], t2 = g4[k + 2 * gsz], t3 = g4[k + 3 * gsz];
+                see4(v0, t0); see4(v1, t1); see4(v2, t2); see4(v3, t3);
+            } else { see4(v0, one); see4(v1, one); see4(v2, one); see4(v3, one); }
         }
-        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) see(p[k]);
+        for (; k < n4; k += gsz) see4(p4[k], GATED ? g4[k] : one);
+        for (int64_t t = (n4 << 2) + gid; t < n; t += gsz) see(p[t], GATED ? gate[t] : 1.f);
     } else {
-        for (int64_t k = gid; k < n; k += gsz) see(p[k]);
+        for (int64_t k = gid; k < n; k += gsz) see(p[k], GATED ? gate[k] : 1.f);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, off)); }
     // one atomic per workgroup: a single word saturates near 88 atomics/us (MI355X_MICROARCH.md
     // "dequeue"), so per-wave atomics from a 2048-block grid alone cost ~90 us
-    __shared__ uint32_t wmax[4], wlo[4];
+    __shared__ uint32_t wmax[kAbsmaxThreads / 64], wlo[kAbsmaxThreads / 64];
     if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wlo[threadIdx.x >> 6] = lo; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-        lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
+        const int nwv = (int)(blockDim.x >> 6);
+        m = 0; lo = 0;
+        for (int w = 0; w < nwv; ++w) { m = max(m, wmax[w]); lo = max(lo, wlo[w]); }
         if (m) atomicMax(out, m);
         if (lo && out_lo) atomicMax(out_lo, lo);
         if (out_lo && blockIdx.x == 0) { out_lo[2] = guard_cap; if (guard_pow) out_lo[5] = guard_pow; }   // (words k + 4 and, for X, 7: range_is_wide)
     }
 }
-
+__global__ __launch_bounds__(kAbsmaxThreads) void absmax_kernel(const float* __restrict__ p, int64_t n,
+                                                                uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
+    absmax_body<false>(p, nullptr, n, out, out_lo, guard_cap, guard_pow);
+}
 // absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
-__global__ __launch_bounds__(256) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
-    uint32_t m = 0, lo = 0;
-    auto see = [&](float f, float gt) {
-        const uint32_t b = gt > 0.0f ? __float_as_uint(f) & 0x7fffffffu : 0u;
-        m = max(m, b);
-        lo = max(lo, (b - 1u < 0x7f7fffffu) ? 0x7f800000u - b : 0u);
-    };
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gate)) & 15) == 0) {   // (scalar loads: 85 us for 2 x 60 MB)
-        const int64_t n4 = n >> 2;
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        const float4* g4 = reinterpret_cast<const float4*>(gate);
-        for (int64_t k = gid; k < n4; k += gsz) {
-            const float4 v = p4[k], gt = g4[k];
-            see(v.x, gt.x); see(v.y, gt.y); see(v.z, gt.z); see(v.w, gt.w);
-        }
-        for (int64_t k = (n4 << 2) + gid; k < n; k += gsz) see(p[k], gate[k]);
-    } else {
-        for (int64_t k = gid; k < n; k += gsz) see(p[k], gate[k]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, off)); }
-    __shared__ uint32_t wmax[4], wlo[4];
-    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wlo[threadIdx.x >> 6] = lo; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-        lo = max(max(wlo[0], wlo[1]), max(wlo[2], wlo[3]));
-        if (m) atomicMax(out, m);
-        if (lo && out_lo) atomicMax(out_lo, lo);
-        if (out_lo && blockIdx.x == 0) { out_lo[2] = guard_cap; if (guard_pow) out_lo[5] = guard_pow; }   // (words k + 4 and, for X, 7: range_is_wide)
-    }
+__global__ __launch_bounds__(kAbsmaxThreads) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
+    absmax_body<true>(p, gate, n, out, out_lo, guard_cap, guard_pow);
 }
 
 // One thread per 16-byte output chunk (8 halves).  Rows: N real + 1 all-zero sentinel row that
@@ -2061,13 +2050,13 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 32, stream));
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
-        const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, hdr, hdr + 2, gx.cap, gx.pow);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, hdr, hdr + 2, gx.cap, gx.pow);
+        const int grid = absmax_grid(nx);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, d_X, d_gate, nx, hdr, hdr + 2, gx.cap, gx.pow);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, d_X, nx, hdr, hdr + 2, gx.cap, gx.pow);
     }
     if (d_val && plan->E > 0 && !block_of_wider) {
-        const int grid = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_val, plan->E, hdr + 1, hdr + 3, guard_spmm(plan).cap, 0u);
+        const int grid = absmax_grid(plan->E);
+        hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, d_val, plan->E, hdr + 1, hdr + 3, guard_spmm(plan).cap, 0u);
     }
     const int64_t chunks = ((int64_t)plan->Nc + 1) * (dpad / 8);
     const unsigned cgrid = (unsigned)((chunks + 255) / 256);
@@ -2842,12 +2831,12 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         uint32_t* whdr = static_cast<uint32_t*>(ws);
         HIP_TRY(hipMemsetAsync(whdr, 0, 32, stream));
         const int64_t nx = (int64_t)plan->Nc * D;
-        const int grid = (int)std::min<int64_t>(512, (nx / 4 + 255) / 256 + 1);
-        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(256), 0, stream, d_X, d_gate, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
-        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, d_X, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
+        const int grid = absmax_grid(nx);
+        if (d_gate) hipLaunchKernelGGL(absmax_gated_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, d_X, d_gate, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
+        else hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, stream, d_X, nx, whdr, whdr + 2, guard_spmm(plan).cap, 1u);
         if (d_val && plan->E > 0) {
-            const int g2 = (int)std::min<int64_t>(512, (plan->E / 4 + 255) / 256 + 1);
-            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, stream, d_val, plan->E, whdr + 1, whdr + 3, guard_spmm(plan).cap, 0u);
+            const int g2 = absmax_grid(plan->E);
+            hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(kAbsmaxThreads), 0, stream, d_val, plan->E, whdr + 1, whdr + 3, guard_spmm(plan).cap, 0u);
         }
         HIP_TRY(hipGetLastError());
         for (int c0 = 0; c0 < D; c0 += kMaxGatherBlockDims) {
@@ -3413,8 +3402,8 @@ int tcgnn_x16_pitch(int32_t D) { return D < 1 ? 0 : x16_pitch(round_up(D, 16)); 
 int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream_v) {
     if (n < 0 || (n > 0 && !d_X) || !d_word) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_absmax: null argument");
     if (n == 0) return TCGNN_OK;
-    const int grid = (int)std::min<int64_t>(512, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr, 0u, 0u);
+    const int grid = absmax_grid(n);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(kAbsmaxThreads), 0, static_cast<hipStream_t>(stream_v), d_X, n, d_word, (uint32_t*)nullptr, 0u, 0u);
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }
