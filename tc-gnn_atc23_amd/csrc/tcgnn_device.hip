@@ -568,6 +568,16 @@ __device__ __forceinline__ void fill_afrag_table(char* tab) {
 
 // Per-tile metadata travels as ONE 256-byte DMA: lane l < 32 fetches cols[t][l], lanes 32..47
 // mask[t][l-32], lanes 48..63 ebase[t][l-48]; it lands lane-linear in a per-wavefront pad.
+#ifndef TCGNN_NT_STORES
+#define TCGNN_NT_STORES 0   // 1: the fused AGNN kernel's score / slice-addend stores are non-temporal (A/B experiments)
+#endif
+template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if TCGNN_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 #ifndef TCGNN_META_AUX
 #define TCGNN_META_AUX 0   // cache policy of the metadata stream (bit 1 = nt): A/B experiments
 #endif
@@ -1312,6 +1322,24 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs 
 //   backward (BWD = true):  att = fl32(w * ef_saved) (edge values DMA'd one tile ahead),
 //            scores of dY are only reduced against the column ids: sum_e s[e] * (float)col(e).
 // ------------------------------------------------------------------------------------------
+// eight 4-byte LDS reads at per-lane addresses, retired before anything else is issued (agnn_kernel backward: the saved scores of
+// this lane's eight tile columns, picked out of its run by address instead of by a cascade of selects)
+__device__ __forceinline__ void lds_read8_b32(const uint32_t (&ad)[8], uint32_t (&v)[8]) {
+    asm volatile("ds_read_b32 %0, %8\n\t"
+                 "ds_read_b32 %1, %9\n\t"
+                 "ds_read_b32 %2, %10\n\t"
+                 "ds_read_b32 %3, %11\n\t"
+                 "ds_read_b32 %4, %12\n\t"
+                 "ds_read_b32 %5, %13\n\t"
+                 "ds_read_b32 %6, %14\n\t"
+                 "ds_read_b32 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                 : "memory");
+}
+
+static constexpr int kAgnnXcds = 8;   // workgroup b runs on XCD b % 8
 struct AgnnArgs {
     const int64_t* wb_ptr;
     const int32_t* order;
@@ -1331,6 +1359,7 @@ struct AgnnArgs {
     const uint32_t* bptr;      // range-major walk (MAXW > 0): per-window tile offsets of the column buckets
     int32_t nbuckets, gsel, nranges, nw, ngroups;
     int32_t big;               // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
+    int32_t nslices;           // > 0 (MAXW = 0 only): the XCD-sliced walk, see agnn_kernel
 };
 
 static constexpr int agnn_wave_lds(int ks, bool bwd) {
@@ -1347,7 +1376,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     constexpr int KS = (NT + 1) / 2;
     constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
     constexpr int CAP = kSddmmStageCap;
-    constexpr int NQ = 2 * KS + (BWD ? 2 : 0);
+    constexpr int NQ = 2 * KS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -1380,7 +1409,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     uint32_t qaddr[NQ];
 #pragma unroll
     for (int k = 0; k < 2 * KS; ++k) qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-    if constexpr (BWD) { qaddr[2 * KS] = aux + (uint32_t)lane * 16u; qaddr[2 * KS + 1] = aux + 1024u + (uint32_t)lane * 16u; }
+    [[maybe_unused]] const uint32_t vaddr0 = aux + (uint32_t)lane * 16u;   // backward: this lane's run of saved scores (second block: + 1024)
     const uint32_t caddr[2] = {pad + 32u * (uint32_t)g, pad + 32u * (uint32_t)g + 16u};   // ids of my eight tile columns (backward)
     // transpose reads: this lane addresses k row j = i >> 2 (row m = 4g + j of half h), feature quad q = i & 3 of slice s
     uint32_t raddr[NT][2];
@@ -1423,7 +1452,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
                 const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
                 if ((uint32_t)lane < c_r) {
-                    *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
+                    st_stream(reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)), vals[r]);
                     const uint32_t ab = vals[r] & 0x7fffffffu;           // max |ef| for the backward call's scale
                     emax = ab > emax ? ab : emax;
                 }
@@ -1452,10 +1481,11 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         // saved scores of row i inside my eight tile columns: one run of ef.  Four floats (clamped to stay inside ef)
         // cover it almost always; a second DMA fetches the next four when some lane's run is longer.
         auto dma_vals = [&](Cur& c) {
-            const int64_t e0 = (int64_t)(int32_t)c.eb + __popc(c.m & low8);
-            int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
-            if (lo < 0) lo = 0;
-            c.sh = (int)(e0 - lo);
+            // (32-bit arithmetic: edge offsets are int32 by the CSR's type)
+            const int32_t e0 = (int32_t)c.eb + __popc(c.m & low8);
+            int32_t lo = min(e0, (int32_t)a.E - 8);
+            lo = max(lo, 0);
+            c.sh = e0 - lo;
             c.wide = __any(__popc((c.m >> (8 * g)) & 0xffu) + c.sh > 4);
             __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)aux, 16, 0, 0);
             if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo + 4), (LDS_AS void*)(uintptr_t)(aux + 1024), 16, 0, 0);
@@ -1465,7 +1495,26 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             uint32_t v[4];
             uintx4 q[NQ];
             lds_ids_block<4>(idaddr, v, qaddr[0], q[0]);          // next tile: two row ids, my row's mask and edge offset; + operand 0
-            lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands [+ my saved scores]
+            lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands
+            // backward: the saved score of tile column j of my eight is word (edges of row i left of it in my run) of the run the
+            // DMA fetched - read by ADDRESS (r03; a cascade of selects over eight registers cost ten VALU instructions per column
+            // in a loop that is VALU-bound: 265 per tile, SQ_INSTS_VALU of profiles/r02).  Lanes without the edge read a
+            // neighbouring word that the mask removes below.
+            [[maybe_unused]] uint32_t sv[8];
+            if constexpr (BWD) {
+                const uint32_t byte0 = (cur.m >> (8 * g)) & 0xffu;
+                uint32_t va = vaddr0 + ((uint32_t)cur.sh << 2), ad[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ad[j] = va;
+                    va -= (uint32_t)((int32_t)(byte0 << (31 - j)) >> 31) << 2;        // + 4 where the edge exists
+                }
+                if (cur.wide) {   // (wave-uniform, rare: some lane's run crosses into the second block of four)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ad[j] += (((ad[j] - vaddr0) >> 4) & 1u) * 1008u;
+                }
+                lds_read8_b32(ad, sv);
+            }
             Cur nx;
             nx.m = v[2]; nx.eb = v[3]; nx.sh = 0; nx.wide = false;
             if constexpr (BWD) lds_q_block<2, 0>(caddr, nx.c);
@@ -1498,23 +1547,18 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             // (the tile loop is VALU-bound - 160 VALU instructions per tile before this form - so the eight columns are
             // handled with masks instead of compares and selects: mk = all-ones where the edge exists; the second scale
             // factor is 1.0 unless the exponent needs two steps, and multiplying by it is exact)
-            [[maybe_unused]] uint32_t kpos = 0u;                // backward: rank of column j among row i's edges inside my run
             [[maybe_unused]] uint32_t wpos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);   // forward: its staging slot
             uint32_t rb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);   // (one v_bfe_i32)
                 const float sraw = S[j >> 2][j & 3];
-                const float sc = (sraw * inv_a) * inv_b;
+                [[maybe_unused]] const float sc = (sraw * inv_a) * inv_b;
                 float att_s;
                 if constexpr (BWD) {
-                    const uint32_t kk = kpos + (uint32_t)cur.sh;                     // position in the eight fetched floats
-                    const floatx4 sv = __builtin_bit_cast(floatx4, (kk & 4u) ? q[2 * KS + 1] : q[2 * KS]);
-                    const float v01 = (kk & 1u) ? sv[1] : sv[0];
-                    const float v23 = (kk & 1u) ? sv[3] : sv[2];
-                    att_s = ((kk & 2u) ? v23 : v01) * c_val;                         // = fl32(w * ef) * 2^ka
-                    dsum += __uint_as_float(__float_as_uint(sc * (float)(int32_t)cur.c[j >> 2][j & 3]) & mk);
-                    kpos -= mk;
+                    att_s = __uint_as_float(sv[j]) * c_val;                          // = fl32(w * ef) * 2^ka
+                    // (the raw accumulator: its power-of-two scale is applied once, to the workgroup's sum)
+                    dsum += __uint_as_float(__float_as_uint(sraw) & mk) * (float)(int32_t)cur.c[j >> 2][j & 3];
                 } else {
                     lds_write_b32(bitfield_select(mk, wpos, junk), sc);
                     wpos -= mk << 2;
@@ -1581,13 +1625,34 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     [[maybe_unused]] int w0 = 0;
     [[maybe_unused]] floatx4 acc0[NT];
     if constexpr (MAXW == 0) {
-        w0 = a.order[blockIdx.x];
-        const int64_t tb = a.wb_ptr[w0], te_w = a.wb_ptr[w0 + 1];
-        const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
-        const int64_t t0 = tb + wave * chunk;
 #pragma unroll
         for (int s = 0; s < NT; ++s) acc0[s] = floatx4{0.f, 0.f, 0.f, 0.f};
-        run(w0, t0, t0 + chunk < te_w ? t0 + chunk : te_w, acc0);
+        if (a.nslices > 0) {
+            // XCD-sliced walk (r03).  Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and here
+            // workgroup b only ever gathers rows of column slice b % nslices: an XCD's 4 MB L2 then holds the one slice of the fp16
+            // image it is asked for (Reddit shape, D = 64: 29.8 MB / 8) instead of seeing all of it - tools/gather_bench.hip: rows out
+            // of an L2-resident slice arrive at 14-17 TB/s against 8.3 TB/s for rows of the whole image, which is what the
+            // per-window walk runs at.  Every wavefront takes the tiles of ONE window inside the slice (bptr: the plan's bucket
+            // table) and stores its sums as that slice's addend of Y (a.y = nslices buffers), which agnn_slice_sum_kernel adds in
+            // slice order: deterministic, and nothing depends on the placement being what is assumed here.
+            // (more than eight slices - an image of 16 .. 32 MB - go in ROUNDS of eight: the grid's first 1 / rounds takes slices
+            //  0 .. 7, the next one slices 8 .. 15, and workgroups start in grid order, so an XCD is asked for one slice at a time)
+            const unsigned per_round = gridDim.x / (unsigned)(a.nslices / kAgnnXcds), b2 = blockIdx.x % per_round;
+            const int slice = (int)(blockIdx.x / per_round) * kAgnnXcds + (int)(b2 % (unsigned)kAgnnXcds);
+            const int wi = (int)(b2 / (unsigned)kAgnnXcds) * WAVES + wave;
+            w0 = wi < a.nw ? __builtin_amdgcn_readfirstlane(a.order[wi]) : -1;
+            if (w0 >= 0) {
+                const int64_t tb = a.wb_ptr[w0];
+                const uint32_t* bp = a.bptr + (int64_t)w0 * (a.nbuckets + 1);
+                run(w0, tb + bp[slice * a.gsel], tb + bp[(slice + 1) * a.gsel], acc0);
+            }
+        } else {
+            w0 = a.order[blockIdx.x];
+            const int64_t tb = a.wb_ptr[w0], te_w = a.wb_ptr[w0 + 1];
+            const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
+            const int64_t t0 = tb + wave * chunk;
+            run(w0, t0, t0 + chunk < te_w ? t0 + chunk : te_w, acc0);
+        }
     } else {
         const int gw = blockIdx.x * WAVES + wave, gwn = gridDim.x * WAVES;
         for (int grp = gw; grp < a.ngroups; grp += gwn) {
@@ -1621,7 +1686,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
 
     if constexpr (BWD) {
         // sum_e score(e) * col(e): per-wavefront double, then one slot per workgroup (fixed order -> deterministic)
-        double d = (double)dsum;
+        double d = (double)dsum * (double)inv_a * (double)inv_b;   // (dsum holds raw MFMA sums: scores * 2^(2 kx))
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
         __syncthreads();
@@ -1644,7 +1709,23 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
 
     // ---- per-window workgroups: combine the wavefronts' partial sums in a fixed order and store
     if constexpr (MAXW == 0) {
-        if constexpr (WAVES > 1) {
+        if (a.nslices > 0) {   // a wavefront = a window: its sums are one slice's addend
+            if (w0 >= 0) {
+                const unsigned per_round = gridDim.x / (unsigned)(a.nslices / kAgnnXcds);
+                const int slice = (int)(blockIdx.x / per_round) * kAgnnXcds + (int)((blockIdx.x % per_round) % (unsigned)kAgnnXcds);
+                const int64_t row0 = (int64_t)w0 * kWinRows + 4 * g;
+                float* const yp = a.y + (int64_t)slice * a.N * a.D;
+#pragma unroll
+                for (int s = 0; s < NT; ++s) {
+                    const int colg = 16 * s + i;
+                    if (colg < a.D) {
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+                            if (row0 + ii < a.N) st_stream(&yp[(row0 + ii) * a.D + colg], acc0[s][ii] * inv1 * inv2);
+                    }
+                }
+            }
+        } else if constexpr (WAVES > 1) {
             __syncthreads(); // every wave is done with its LDS
             floatx4* red = reinterpret_cast<floatx4*>(smem);
 #pragma unroll
@@ -1662,6 +1743,26 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         } else {
 #pragma unroll
             for (int s = 0; s < NT; ++s) store_rows(w0, s, acc0[s]);
+        }
+    }
+}
+
+// Y = sum of the XCD-sliced walk's addends, in slice order (float4 where the pointers allow)
+__global__ __launch_bounds__(256) void agnn_slice_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int64_t n, int64_t stride, int32_t nslices) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    if (((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && ((n | stride) & 3) == 0) {
+        const int64_t n4 = n >> 2, s4 = stride >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(part);
+        for (int64_t k = gid; k < n4; k += gsz) {
+            float4 v = p4[k];
+            for (int s = 1; s < nslices; ++s) { const float4 o = p4[(int64_t)s * s4 + k]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            reinterpret_cast<float4*>(y)[k] = v;
+        }
+    } else {
+        for (int64_t k = gid; k < n; k += gsz) {
+            float v = part[k];
+            for (int s = 1; s < nslices; ++s) v += part[(int64_t)s * stride + k];
+            y[k] = v;
         }
     }
 }
@@ -1997,8 +2098,12 @@ static size_t workspace_bytes_for(int32_t N, int32_t D) {
     const size_t body = ((size_t)N + 1) * dpad * sizeof(_Float16);
     return kHdrBytes + ((body + 255) / 256) * 256;
 }
-// the fused AGNN backward keeps one double per workgroup (= per window) behind the fp16 image
-static size_t agnn_partial_bytes(const tcgnn_plan* plan) { return (((size_t)std::max(plan->nw_eff, 1) * sizeof(double)) + 255) / 256 * 256; }
+// the fused AGNN backward keeps one double per workgroup (per window; the XCD-sliced walk: per slice and four windows) behind the fp16 image
+static constexpr int kAgnnMaxSlices = 16;   // two rounds of eight (= XCDs)
+static size_t agnn_partial_bytes(const tcgnn_plan* plan) {
+    const size_t slots = std::max<size_t>((size_t)std::max(plan->nw_eff, 1), (size_t)kAgnnMaxSlices * (((size_t)std::max(plan->nw_eff, 1) + 3) / 4));
+    return (slots * sizeof(double) + 255) / 256 * 256;
+}
 
 // enqueue absmax(X) [+ absmax(val)] + convert; returns the fp16 image pointer
 // The range-blocked walks bind up to 4 windows to one persistent wavefront for the whole launch: a hub window (skewed
@@ -2015,6 +2120,32 @@ static bool windows_balanced(const tcgnn_plan* plan) {
 // 6250 windows the range-blocked walk left the chip a quarter full (0.33 / 1.03 ms against 0.13 / 0.66 ms per-window).
 static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
     return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
+}
+// The fused AGNN kernel's XCD-sliced walk (agnn_kernel): when one eighth of the fp16 image fits an XCD's 4 MB L2 and the whole image
+// does not (Reddit shape at D <= 64), on graphs whose numbering carries no locality of its own and whose windows are alike.
+// It costs nslices addends of Y in the workspace and a pass that sums them.  TCGNN_AGNN_SLICED: 0 never, 2 whenever possible.
+// Measured on the Reddit shape (tools/bench_agnn.py, forward / backward): D = 32 (14.9 MB image, 1.86 MB slices) 1.45 / 1.66 ->
+// 1.27 / 1.39 ms, D = 16 1.19 / 1.44 -> 1.16 / 1.30; D = 64 in eight slices of 3.7 MB 1.79 / 1.92 -> 1.85 / 2.02 (the slice does
+// not stay resident beside the streams that pass through the same L2), in sixteen (two rounds) 2.03 / 2.21 (twice the addends,
+// runs of 15 tiles): the automatic rule stops at 2 MB slices in one round; the two-round form is reachable by request only.
+static constexpr size_t kAgnnSliceBytes = (size_t)2 << 20;
+// -> number of slices (8 or 16), 0: the per-window walk.  TCGNN_AGNN_SLICED (read per call: tests switch it): 0 never, 2 whenever
+// possible, 16 two rounds whenever possible.
+static int agnn_slices(const tcgnn_plan* plan, int32_t D) {
+    const char* const env = getenv("TCGNN_AGNN_SLICED");
+    const int g_agnn_sliced = env ? atoi(env) : 1;
+    if (!g_agnn_sliced || plan->waves != 4 || plan->nbuckets < 8 || plan->nw_eff < 1) return 0;
+    const int pitch = x16_pitch(round_up(D, 16));
+    if (image_is_big(plan->Nc, pitch)) return 0;
+    const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
+    const int ns = kAgnnXcds;
+    if (plan->nbuckets % ns) return 0;
+    if (g_agnn_sliced >= 2) return (g_agnn_sliced == 16 && plan->nbuckets % 16 == 0) ? 16 : ns;   // (forced)
+    return (x16_bytes > kBlockedMinBytes && x16_bytes <= (size_t)ns * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
+            windows_balanced(plan) && !has_locality(plan)) ? ns : 0;
+}
+static size_t agnn_slice_bytes(const tcgnn_plan* plan, int32_t D) {
+    return ((size_t)agnn_slices(plan, D) * (size_t)plan->N * D * sizeof(float) + 255) / 256 * 256;
 }
 
 // ---- range guard parameters (range_is_wide): cap = how many lost-precision terms one result can collect at most - the longest row
@@ -2979,7 +3110,9 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         return fail(TCGNN_ERR_UNSUPPORTED, "%s: needs a canonical plan, D <= %d and E >= 8 (canonical=%d, D=%d, E=%lld)", name,
                     kMaxChunkDims, plan->canonical, D, (long long)plan->E);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan);
+    const int nslices = agnn_slices(plan, D);
+    const bool sliced = nslices > 0;
+    const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D);
     if (!ws || ws_bytes < need) return fail(TCGNN_ERR_WORKSPACE, "%s: workspace needs %zu bytes, got %zu", name, need, ws_bytes);
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) {   // rows the caller's windows do not cover stay zero
         HIP_TRY(hipMemsetAsync(d_Y, 0, (size_t)plan->N * D * sizeof(float), stream));
@@ -2997,9 +3130,10 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
                plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
-               image_is_big(plan->Nc, pitch)};
+               image_is_big(plan->Nc, pitch), 0};
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
+    float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
     // The range-major variant exists and is bit-compatible, but measured slower for the fused kernel on the Reddit shape
     // (D=64: 1.87 vs 1.80 ms forward, 2.39 vs 1.90 ms backward; D=32 forward is the one exception, 1.28 vs 1.55): the
     // fused loop is bound by issue slots and wavefront count (PMC: VALU+MFMA ~60 % of SIMD time, 3 instead of 4 waves
@@ -3007,9 +3141,21 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
     {
-        KernelTimer timer(plan, stream, "agnn_kernel");
+        KernelTimer timer(plan, stream, (sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel");
         hipError_t e;
-        if (blocked) {
+        if (sliced && !blocked) {
+            a.nslices = nslices;
+            a.gsel = plan->nbuckets / nslices;
+            a.y = ypart;
+            nwg = nslices * ((plan->nw_eff + 3) / 4);
+            e = bwd ? launch_agnn<4, true, 0>(nt, a, nwg, stream) : launch_agnn<4, false, 0>(nt, a, nwg, stream);
+            if (e == hipSuccess) {
+                const int64_t nsum = std::min<int64_t>(plan->N, (int64_t)plan->nw_eff * kWinRows) * D;   // (rows beyond the windows were zeroed above)
+                const unsigned sg = (unsigned)std::min<int64_t>(2048, (nsum / 4 + 255) / 256 + 1);
+                hipLaunchKernelGGL(agnn_slice_sum_kernel, dim3(sg), dim3(256), 0, stream, ypart, d_Y, nsum, (int64_t)plan->N * D, nslices);
+                e = hipGetLastError();
+            }
+        } else if (blocked) {
             size_t range_bytes = 4 * kRangeTargetBytes;
             if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
             int nranges = 1;
@@ -3375,7 +3521,7 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
         }
         if (all_built && !cold_rows) two_images = false;
     }
-    return image + std::max({agnn_partial_bytes(plan), two_images ? image : (size_t)0});
+    return image + std::max({agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D), two_images ? image : (size_t)0});
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {

@@ -589,6 +589,49 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
             assert np.abs(gemm["0"][0].cpu().numpy() - Z.cpu().numpy()).max() <= TIGHT * scale
 
 
+@pytest.mark.parametrize("D", [16, 41, 64])
+def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatch):
+    """r03: the XCD-sliced walk of the fused kernel (workgroup b gathers only rows of column slice b % 8, so an XCD's L2 holds the
+    slice it is asked for; a wavefront = one window's tiles inside the slice; the slices' addends of Y summed in slice order by
+    agnn_slice_sum_kernel).  Automatic for images of 6 - 16 MB, forced here (TCGNN_AGNN_SLICED = 2: eight slices, 16: two rounds
+    of eight) on a graph the oracle can handle, N % 16 != 0: same scores bit for bit, same aggregation up to accumulation order,
+    same d_w, deterministic."""
+    rp, col = graphs.uniform_graph(70003, 80, seed=14)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    assert T.plan_info(*meta)["column_buckets"] % 16 == 0
+    rng = np.random.default_rng(D + 9)
+    H = (rng.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
+    dY = rng.standard_normal((n, D)).astype(np.float32)
+    tH, tdY = to_dev(dev, H, dY)
+    tw = torch.tensor([-1.3], device=dev)
+    out = {}
+    for sl in ("0", "2", "16"):
+        monkeypatch.setenv("TCGNN_AGNN_SLICED", sl)
+        Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
+        kf = T.last_kernel(*meta)
+        G, dw = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
+        G2, dw2 = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
+        assert torch.equal(G, G2) and torch.equal(dw, dw2)
+        assert ("XCD-sliced" in kf) == (sl != "0") and ("XCD-sliced" in T.last_kernel(*meta)) == (sl != "0"), (sl, kf)
+        out[sl] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax.item(), G.cpu().numpy(), float(dw))
+    att = (np.float32(-1.3) * out["0"][1]).astype(np.float32)
+    Y64, absY = O.spmm_f64(H, rp, col, att)
+    G64, absG = O.spmm_f64(dY, rp, col, att)
+    refY = O.spmm_val(H, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    refG = O.spmm_val(dY, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
+    want = float((d_att * col).sum()); term_scale = float((np.abs(d_att) * col).sum()) + 1.0
+    for sl in ("2", "16"):
+        Y, ef, efm, G, dw = out[sl]
+        assert np.array_equal(ef, out["0"][1]) and efm == out["0"][2]
+        assert_parity(Y, refY, Y64, absY, "Y sliced %s" % sl)
+        assert_parity(G, refG, G64, absG, "G sliced %s" % sl)
+        assert np.abs(Y - out["0"][0]).max() <= TIGHT * (absY.max() + 1.0) and np.abs(G - out["0"][3]).max() <= TIGHT * (absG.max() + 1.0)
+        assert abs(dw - want) <= 1e-6 * term_scale, (dw, want, term_scale)
+
+
 @pytest.mark.parametrize("D", [16, 48, 64, 96, 128])
 def test_lds_resident_walk_with_a_cold_remainder(dev, T, D, monkeypatch):
     """A graph with communities: the (workgroup, column range) pairs that hold few of a workgroup's columns are left out of the
