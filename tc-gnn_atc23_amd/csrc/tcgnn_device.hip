@@ -2947,7 +2947,12 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             else any_cold = any_cold || ci.cold_tiles > 0;
             thin = thin || ci.hot_cols * 2 < ci.hot_cols + ci.cold_cols;
         }
-        if ((any_cold && (npass > 1 || d_W)) || (flat_cold && d_W)) lds = false;
+        if ((any_cold && (npass > 1 || d_W)) || (flat_cold && d_W)) {
+            lds = false;
+            // (a width whose passes can never share one remainder: settle the choice, so later calls - and tcgnn_workspace_bytes, which
+            //  reserves a second image for LDS-chosen widths - stop coming back here)
+            if (any_cold && npass > 1 && mode != 3 && round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0;
+        }
         else if (thin && mode != 3) { lds = false; if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0; }
         else if (any_cold) cold = &c0;
     }

@@ -103,3 +103,34 @@ def test_refusals(tmp_path):
     save_npz(tmp_path / "rect.npz", coo_matrix((np.ones(2), ([0, 1], [2, 3])), shape=(4, 6)))
     with pytest.raises(ValueError, match="not square"):
         C.convert(str(tmp_path / "rect.npz"), str(tmp_path / "o.npz"))
+
+
+def test_bench_uses_a_real_graph_file_when_one_is_on_the_box(tmp_path, monkeypatch):
+    """bench.py looks for the real Reddit / ogbn-products files and measures them when present (it says so in
+    `data`); with nothing there it measures the synthetic shape.  The finder and the loader, on fabricated files."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("TCGNN_DATA_DIR", str(tmp_path))
+    monkeypatch.setenv("HOME", str(tmp_path / "nohome"))
+    if not any(os.path.exists(os.path.join(r, f)) for r in (os.path.join(ROOT, "dataset"), "/data") for f in bench.REAL_GRAPH_FILES["reddit"]):
+        assert bench.find_real_graph("reddit") is None
+    s, d = edges()
+    (tmp_path / "reddit").mkdir()
+    save_npz(tmp_path / "reddit" / "reddit_graph.npz", coo_matrix((np.ones(len(s)), (s, d)), shape=(N, N)))
+    found = bench.find_real_graph("reddit")
+    assert found == str(tmp_path / "reddit" / "reddit_graph.npz")
+    rp, col = bench.load_real_graph(found, "cpu")
+    want_rp, want_col = csr_of(s, d, N)
+    assert np.array_equal(rp.numpy(), want_rp) and np.array_equal(col.numpy(), want_col)
+    np.savez(tmp_path / "reddit.npz", src_li=s, dst_li=d, num_nodes=N)        # the reference's own schema is taken first
+    assert bench.find_real_graph("reddit") == str(tmp_path / "reddit.npz")
+    rp2, col2 = bench.load_real_graph(str(tmp_path / "reddit.npz"), "cpu")
+    assert np.array_equal(rp2.numpy(), want_rp) and np.array_equal(col2.numpy(), want_col)
+    raw = tmp_path / "ogbn_products" / "raw"; raw.mkdir(parents=True)          # an OGB raw directory: each undirected edge once
+    with gzip.open(str(raw / "edge.csv.gz"), "wt") as f:
+        f.write("".join("%d,%d\n" % (a, b) for a, b in zip(s, d)))
+    with gzip.open(str(raw / "num-node-list.csv.gz"), "wt") as f:
+        f.write("%d\n" % N)
+    rp3, col3 = bench.load_real_graph(bench.find_real_graph("ogbn-products"), "cpu")
+    w3 = csr_of(np.concatenate([s, d]), np.concatenate([d, s]), N)
+    assert np.array_equal(rp3.numpy(), w3[0]) and np.array_equal(col3.numpy(), w3[1])
