@@ -1404,11 +1404,43 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     for (int ks = 0; ks < KS; ++ks) boff[ks] = (ks * 32 + 8 * g < a.Dpad) ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u;
     // pad: cols[32] | mask[16] | ebase[16]; this lane: ids of the tile columns it gathers for the two halves
     // (row m = i of half sub is tile column 8(i>>2) + 4sub + (i&3)), mask and edge offset of ROW i
+    //
+    // WL (KS = 2, rows of one 128-byte line; r03): WHOLE-LINE gathers.  The layout above makes an instruction take 64 bytes of each
+    // of sixteen rows, so every line is asked for twice, and tools/gather_bench.hip measures what that costs once the rows come out
+    // of L2: 9.2 TB/s at any depth against 14-18 TB/s for instructions that take eight whole rows.  Here instruction q takes the
+    // rows of tile columns 8q .. 8q+7 - lane L the 16-byte chunk of row slot rho = L >> 3 that belongs at position p = L & 7 - into
+    // block q, row-major.  Chunk c of row slot rho lies at position c ^ sw(rho, q), sw = 4 ((rho >> 1) & 1) + sigma(q),
+    // sigma = (0, 2, 3, 1): with it the sixteen lanes of every ds_read_b128 lane group of MFMA #1's operand reads (row i, chunk
+    // 4 ks + g) fall into the sixteen 16-byte bank slots, and so do the eight rows x two chunks a 32-lane group of the transposed
+    // reads of MFMA #2 addresses.  All of it is per-lane constants: the tile loop issues the same instructions as before, plus two
+    // more row ids read from the pad.
+    constexpr bool WL = KS == 2;
+    constexpr int NV = WL ? 6 : 4;                                   // words read from the pad per tile: row ids, mask, edge offset
+    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t { return 4u * ((rho >> 1) & 1u) + ((0x1320u >> (4u * q)) & 3u); };
     const uint32_t pcol = (uint32_t)(8 * (i >> 2) + (i & 3));
-    const uint32_t idaddr[4] = {pad + pcol * 4u, pad + (pcol + 4u) * 4u, pad + 128u + (uint32_t)i * 4u, pad + 192u + (uint32_t)i * 4u};
+    uint32_t idaddr[NV];
+    if constexpr (WL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) idaddr[q] = pad + (uint32_t)(8 * q + (lane >> 3)) * 4u;
+    } else { idaddr[0] = pad + pcol * 4u; idaddr[1] = pad + (pcol + 4u) * 4u; }
+    idaddr[NV - 2] = pad + 128u + (uint32_t)i * 4u;
+    idaddr[NV - 1] = pad + 192u + (uint32_t)i * 4u;
+    [[maybe_unused]] uint32_t choff[4] = {0u, 0u, 0u, 0u};         // WL: byte offset inside the row this lane fetches with instruction q
+    if constexpr (WL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t c = (uint32_t)(lane & 7) ^ wl_sw((uint32_t)(lane >> 3), (uint32_t)q);
+            choff[q] = ((int)(c * 8u) < a.Dpad) ? c * 16u : 0u;      // (a chunk past Dpad: chunk 0 instead - valid memory, multiplied by zeros)
+        }
+    }
     uint32_t qaddr[NQ];
 #pragma unroll
-    for (int k = 0; k < 2 * KS; ++k) qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    for (int k = 0; k < 2 * KS; ++k) {
+        if constexpr (WL) {   // operand (sub, ks) of MFMA #1: row m = i of half sub, chunk 4 ks + g
+            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS), q = (uint32_t)(i >> 2), rho = 4u * sub + (uint32_t)(i & 3);
+            qaddr[k] = ring + q * 1024u + rho * 128u + (((4u * ks + (uint32_t)g) ^ wl_sw(rho, q)) * 16u);
+        } else qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    }
     [[maybe_unused]] const uint32_t vaddr0 = aux + (uint32_t)lane * 16u;   // backward: this lane's run of saved scores (second block: + 1024)
     const uint32_t caddr[2] = {pad + 32u * (uint32_t)g, pad + 32u * (uint32_t)g + 16u};   // ids of my eight tile columns (backward)
     // transpose reads: this lane addresses k row j = i >> 2 (row m = 4g + j of half h), feature quad q = i & 3 of slice s
@@ -1416,8 +1448,13 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            raddr[s][h] = ring + (uint32_t)((h * KS + (s >> 1)) * 1024 + ((2 * (s & 1) + ((i & 3) >> 1)) * 16 + 4 * g + (i >> 2)) * 16 + 8 * (i & 1));
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (WL) {   // row m = 4g + (i >> 2) of half h = row slot 4h + (i >> 2) of block g; features 16 s + 4 (i & 3) ..
+                const uint32_t rho = 4u * (uint32_t)h + (uint32_t)(i >> 2), c = 2u * (uint32_t)s + (uint32_t)((i & 3) >> 1);
+                raddr[s][h] = ring + (uint32_t)g * 1024u + rho * 128u + ((c ^ wl_sw(rho, (uint32_t)g)) * 16u) + 8u * (uint32_t)(i & 1);
+            } else
+                raddr[s][h] = ring + (uint32_t)((h * KS + (s >> 1)) * 1024 + ((2 * (s & 1) + ((i & 3) >> 1)) * 16 + 4 * g + (i >> 2)) * 16 + 8 * (i & 1));
+        }
     const uint32_t stg_i = aux + (uint32_t)i * CAP * 4u;
     const uint32_t junk = aux + 16u * CAP * 4u + (uint32_t)lane * 4u;
     const uint32_t flush_base = aux + (uint32_t)lane * 4u;
@@ -1460,6 +1497,20 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             cnt = 0u; rstart = ~0u;
         };
         auto dma_b = [&](const uint32_t* cid) {
+            if constexpr (WL) {   // four instructions of eight whole rows each
+                if (MAXW == 0 && a.big) {
+                    const char* const xb = reinterpret_cast<const char*>(a.x16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[q] * (uint64_t)(stride * 2) + choff[q]),
+                                                         (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, 0, 0);
+                    return;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, (int)cid[q], (int)choff[q], 0, 0, 0);
+                return;
+            }
             if (MAXW == 0 && a.big) {   // (the range-major variant, on request only, is at its register limit: the launcher keeps big images off it)
                 const char* const xb = reinterpret_cast<const char*>(a.x16);
 #pragma unroll
@@ -1492,9 +1543,9 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         };
         auto stage = [&](Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
             wait_vm0();
-            uint32_t v[4];
+            uint32_t v[NV];
             uintx4 q[NQ];
-            lds_ids_block<4>(idaddr, v, qaddr[0], q[0]);          // next tile: two row ids, my row's mask and edge offset; + operand 0
+            lds_ids_block<NV>(idaddr, v, qaddr[0], q[0]);         // next tile: its row ids for my lane, my row's mask and edge offset; + operand 0
             lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands
             // backward: the saved score of tile column j of my eight is word (edges of row i left of it in my run) of the run the
             // DMA fetched - read by ADDRESS (r03; a cascade of selects over eight registers cost ten VALU instructions per column
@@ -1516,7 +1567,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 lds_read8_b32(ad, sv);
             }
             Cur nx;
-            nx.m = v[2]; nx.eb = v[3]; nx.sh = 0; nx.wide = false;
+            nx.m = v[NV - 2]; nx.eb = v[NV - 1]; nx.sh = 0; nx.wide = false;
             if constexpr (BWD) lds_q_block<2, 0>(caddr, nx.c);
             half4 lo[NT], hi[NT];
             lds_tr_block<NT, 0>(raddr, lo, hi);
@@ -1597,10 +1648,10 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
         wait_vm0();
         Cur cur;
         {
-            uint32_t v[4];
+            uint32_t v[NV];
             uintx4 dummy;
-            lds_ids_block<4>(idaddr, v, qaddr[0], dummy);
-            cur.m = v[2]; cur.eb = v[3]; cur.sh = 0; cur.wide = false;
+            lds_ids_block<NV>(idaddr, v, qaddr[0], dummy);
+            cur.m = v[NV - 2]; cur.eb = v[NV - 1]; cur.sh = 0; cur.wide = false;
             if constexpr (BWD) lds_q_block<2, 0>(caddr, cur.c);
             dma_b(v);
             if constexpr (BWD) dma_vals(cur);
@@ -2121,28 +2172,38 @@ static bool windows_balanced(const tcgnn_plan* plan) {
 static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
     return plan->nbuckets > 0 && x16_bytes / (size_t)plan->nbuckets <= ((size_t)8 << 20) && plan->nw_eff >= 32 * plan->num_cus;
 }
-// The fused AGNN kernel's XCD-sliced walk (agnn_kernel): when one eighth of the fp16 image fits an XCD's 4 MB L2 and the whole image
-// does not (Reddit shape at D <= 64), on graphs whose numbering carries no locality of its own and whose windows are alike.
-// It costs nslices addends of Y in the workspace and a pass that sums them.  TCGNN_AGNN_SLICED: 0 never, 2 whenever possible.
-// Measured on the Reddit shape (tools/bench_agnn.py, forward / backward): D = 32 (14.9 MB image, 1.86 MB slices) 1.45 / 1.66 ->
-// 1.27 / 1.39 ms, D = 16 1.19 / 1.44 -> 1.16 / 1.30; D = 64 in eight slices of 3.7 MB 1.79 / 1.92 -> 1.85 / 2.02 (the slice does
-// not stay resident beside the streams that pass through the same L2), in sixteen (two rounds) 2.03 / 2.21 (twice the addends,
-// runs of 15 tiles): the automatic rule stops at 2 MB slices in one round; the two-round form is reachable by request only.
-static constexpr size_t kAgnnSliceBytes = (size_t)2 << 20;
-// -> number of slices (8 or 16), 0: the per-window walk.  TCGNN_AGNN_SLICED (read per call: tests switch it): 0 never, 2 whenever
-// possible, 16 two rounds whenever possible.
-static int agnn_slices(const tcgnn_plan* plan, int32_t D) {
+// The fused AGNN kernel's walks beside the per-window one (agnn_kernel), for graphs whose numbering carries no locality of its own and
+// whose windows are alike, when the fp16 image does not fit an XCD's 4 MB L2 but an eighth of it does:
+//   XCD-sliced  - nslices addends of Y in the workspace and a pass that sums them;
+//   range-major - persistent wavefronts owning two windows each (no addends; more registers).
+// Measured on the Reddit shape (tools/bench_agnn.py, forward / backward ms; r03 with whole-line gathers at D = 64):
+//   D = 16 (7.4 MB)  per-window 1.13 / 1.43   sliced 1.06 / 1.28   range-major 1.19 / 1.59
+//   D = 32 (14.9 MB) per-window 1.46 / 1.65   sliced 1.20 / 1.38   range-major 1.26 / 1.65
+//   D = 64 (29.8 MB) per-window 1.74 / 1.77   sliced 1.53 / 1.60   range-major 1.45-1.48 / 1.78   (sixteen slices in two rounds 1.81 / 1.85)
+// so: sliced in both directions up to 16 MB; from there to 32 MB range-major forward and sliced backward.
+// TCGNN_AGNN_SLICED (read per call: tests switch it): 0 per-window only, 1 the rule above, 2 sliced whenever possible, 16 two rounds.
+static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
+enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
+static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_out) {
+    *nslices_out = 0;
     const char* const env = getenv("TCGNN_AGNN_SLICED");
-    const int g_agnn_sliced = env ? atoi(env) : 1;
-    if (!g_agnn_sliced || plan->waves != 4 || plan->nbuckets < 8 || plan->nw_eff < 1) return 0;
+    const int knob = env ? atoi(env) : 1;
+    if (!knob || plan->waves != 4 || plan->nbuckets < 8 || plan->nw_eff < 1 || plan->nbuckets % kAgnnXcds) return kAgnnPerWindow;
     const int pitch = x16_pitch(round_up(D, 16));
-    if (image_is_big(plan->Nc, pitch)) return 0;
+    if (image_is_big(plan->Nc, pitch)) return kAgnnPerWindow;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
-    const int ns = kAgnnXcds;
-    if (plan->nbuckets % ns) return 0;
-    if (g_agnn_sliced >= 2) return (g_agnn_sliced == 16 && plan->nbuckets % 16 == 0) ? 16 : ns;   // (forced)
-    return (x16_bytes > kBlockedMinBytes && x16_bytes <= (size_t)ns * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
-            windows_balanced(plan) && !has_locality(plan)) ? ns : 0;
+    if (knob >= 2) { *nslices_out = (knob == 16 && plan->nbuckets % 16 == 0) ? 16 : kAgnnXcds; return kAgnnSliced; }   // (forced)
+    if (!(x16_bytes > kBlockedMinBytes && x16_bytes <= (size_t)kAgnnXcds * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
+          windows_balanced(plan) && !has_locality(plan))) return kAgnnPerWindow;
+    if (!bwd && x16_bytes > (size_t)kAgnnXcds * (kAgnnSliceBytes / 2)) return kAgnnRangeMajor;
+    *nslices_out = kAgnnXcds;
+    return kAgnnSliced;
+}
+// (the workspace is sized for whichever direction slices)
+static int agnn_slices(const tcgnn_plan* plan, int32_t D) {
+    int nf = 0, nb = 0;
+    (void)agnn_walk(plan, D, false, &nf); (void)agnn_walk(plan, D, true, &nb);
+    return std::max(nf, nb);
 }
 static size_t agnn_slice_bytes(const tcgnn_plan* plan, int32_t D) {
     return ((size_t)agnn_slices(plan, D) * (size_t)plan->N * D * sizeof(float) + 255) / 256 * 256;
@@ -3115,8 +3176,9 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         return fail(TCGNN_ERR_UNSUPPORTED, "%s: needs a canonical plan, D <= %d and E >= 8 (canonical=%d, D=%d, E=%lld)", name,
                     kMaxChunkDims, plan->canonical, D, (long long)plan->E);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const int nslices = agnn_slices(plan, D);
-    const bool sliced = nslices > 0;
+    int nslices = 0;
+    const int walk = agnn_walk(plan, D, bwd, &nslices);
+    const bool sliced = walk == kAgnnSliced;
     const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D);
     if (!ws || ws_bytes < need) return fail(TCGNN_ERR_WORKSPACE, "%s: workspace needs %zu bytes, got %zu", name, need, ws_bytes);
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) {   // rows the caller's windows do not cover stay zero
@@ -3139,11 +3201,10 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
-    // The range-major variant exists and is bit-compatible, but measured slower for the fused kernel on the Reddit shape
-    // (D=64: 1.87 vs 1.80 ms forward, 2.39 vs 1.90 ms backward; D=32 forward is the one exception, 1.28 vs 1.55): the
-    // fused loop is bound by issue slots and wavefront count (PMC: VALU+MFMA ~60 % of SIMD time, 3 instead of 4 waves
-    // per SIMD with the extra accumulators), not by gather locality.  Only on request (mode 2).
-    const bool blocked = plan->nbuckets > 0 && g_spmm_mode == 2 && x16_bytes > 0 && !a.big;
+    // The range-major variant (bit-compatible scores, sums in another order): slower than the per-window walk while the kernel
+    // asked for every 128-byte line twice (r02: D = 64 1.87 vs 1.80 ms forward); with whole-line gathers (r03) its forward pass
+    // is the fastest form at D = 64 (1.45-1.48 against 1.74 per-window, 1.53 sliced) - agnn_walk picks it there; mode 2 forces it.
+    const bool blocked = plan->nbuckets > 0 && (g_spmm_mode == 2 || (g_spmm_mode == 0 && walk == kAgnnRangeMajor)) && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
     {
         KernelTimer timer(plan, stream, (sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel");

@@ -117,6 +117,9 @@ int main() {
             char name[64]; snprintf(name, sizeof name, "  in step over %d slices", S);
             printf("%-28s %8.2f %8.2f %8.2f %8.2f\n", name, run<128, 1, 4>(d_ids, d_table, total_tiles, 3, sink), run<128, 2, 4>(d_ids, d_table, total_tiles, 3, sink),
                    run<128, 3, 4>(d_ids, d_table, total_tiles, 3, sink), run<128, 4, 4>(d_ids, d_table, total_tiles, 3, sink));
+            snprintf(name, sizeof name, "    the same, half lines");
+            printf("%-28s %8.2f %8.2f %8.2f %8.2f\n", name, run<128, 1, 4, true>(d_ids, d_table, total_tiles, 3, sink), run<128, 2, 4, true>(d_ids, d_table, total_tiles, 3, sink),
+                   run<128, 3, 4, true>(d_ids, d_table, total_tiles, 3, sink), run<128, 4, 4, true>(d_ids, d_table, total_tiles, 3, sink));
         }
         CK(hipFree(d_table));
         if (getenv("GATHER_BENCH_R03_ONLY")) return 0;
