@@ -596,6 +596,23 @@ struct MetaSource {
 };
 static constexpr int kPadBytes = 256;
 
+// eight 4-byte LDS reads at per-lane addresses, retired before anything else is issued (agnn_kernel backward: the saved scores of
+// this lane's eight tile columns; TileWalker: its edge values - picked out of the lane's run by address instead of by a cascade of selects)
+__device__ __forceinline__ void lds_read8_b32(const uint32_t (&ad)[8], uint32_t (&v)[8]) {
+    asm volatile("ds_read_b32 %0, %8\n\t"
+                 "ds_read_b32 %1, %9\n\t"
+                 "ds_read_b32 %2, %10\n\t"
+                 "ds_read_b32 %3, %11\n\t"
+                 "ds_read_b32 %4, %12\n\t"
+                 "ds_read_b32 %5, %13\n\t"
+                 "ds_read_b32 %6, %14\n\t"
+                 "ds_read_b32 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                 : "memory");
+}
+
 // Per-lane constants and the software-pipelined walk over a run of wide blocks, shared by the
 // per-window kernel (run = every WAVES-th tile of one window) and the range-blocked kernel
 // (run = the tiles of one window inside one column range).
@@ -680,24 +697,12 @@ struct TileWalker {
         if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo + 4), (LDS_AS void*)(uintptr_t)(vpad + 1024u), 16, 0, 0);
     }
 
-    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, const uintx4& q2, floatx4 (&acc)[NT]) const {
+    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, const uint32_t (&sv)[8], floatx4 (&acc)[NT]) const {
         half8 af;
         if constexpr (VAL) {
             const uint32_t mb = (cur.m >> (8 * g)) & 0xffu;
-            const floatx4 vals = __builtin_bit_cast(floatx4, q);
             const int nb = __popc(mb);
-            if (cur.wide) {
-                const floatx4 vals2 = __builtin_bit_cast(floatx4, q2);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = __popc(mb & ((1u << j) - 1u)) + cur.shift;
-                    const floatx4 sv = (k & 4) ? vals2 : vals;
-                    const float v01 = (k & 1) ? sv[1] : sv[0];
-                    const float v23 = (k & 1) ? sv[3] : sv[2];
-                    const float v = (k & 2) ? v23 : v01;
-                    af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
-                }
-            } else if (__builtin_expect(__any(nb + cur.shift > 4), 0)) {
+            if (!cur.wide && __builtin_expect(__any(nb + cur.shift > 4), 0)) {
                 // (fewer than eight edges in the whole matrix) ordinary loads; the compiler drains the DMA queue for them
                 const int64_t e0 = (int64_t)cur.eb + __popc(cur.m & ((1u << (8 * g)) - 1u));
 #pragma unroll
@@ -707,14 +712,10 @@ struct TileWalker {
                     af[j] = to_half_rna(v);
                 }
             } else {
+                // sv[j]: the value of tile column j of my eight, read from the fetched run BY ADDRESS in stage() (r03: the cascade of
+                // selects over the fetched registers cost ~10 VALU instructions per column of a loop that is VALU-bound)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = __popc(mb & ((1u << j) - 1u)) + cur.shift;
-                    const float v01 = (k & 1) ? vals[1] : vals[0];
-                    const float v23 = (k & 1) ? vals[3] : vals[2];
-                    const float v = (k & 2) ? v23 : v01;
-                    af[j] = ((mb >> j) & 1u) ? to_half_rna(v * sa) : (_Float16)0.0f;
-                }
+                for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? to_half_rna(__uint_as_float(sv[j]) * sa) : (_Float16)0.0f;
             }
         } else {
             af = __builtin_bit_cast(half8, q);   // table entry of this lane's adjacency byte
@@ -741,9 +742,20 @@ struct TileWalker {
         uintx4 q;
         const uint32_t qaddr = VAL ? vpad + (uint32_t)lane * 16u : atab + (((cur.m >> (8 * g)) & 0xffu) << 4);
         lds_ids_block<NIDS>(idaddr, v, qaddr, q);
-        uintx4 q2 = q;
-        if constexpr (VAL) {
-            if (cur.wide) { const uint32_t qa2 = qaddr + 1024u; lds_q_block<1, 0>(&qa2, &q2); }   // (before the next tile's values overwrite the pad)
+        [[maybe_unused]] uint32_t sv[8];
+        if constexpr (VAL) {   // (before the next tile's values overwrite the pad)
+            const uint32_t mb = (cur.m >> (8 * g)) & 0xffu, vbase = vpad + (uint32_t)lane * 16u;
+            uint32_t va = vbase + ((uint32_t)cur.shift << 2), ad[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ad[j] = va;
+                va -= (uint32_t)((int32_t)(mb << (31 - j)) >> 31) << 2;                 // + 4 where the edge exists
+            }
+            if (cur.wide) {   // (wave-uniform: some lane's run crosses into the second block of four)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ad[j] += (((ad[j] - vbase) >> 4) & 1u) * 1008u;
+            }
+            lds_read8_b32(ad, sv);
         }
         const bool more = tn < te;
         Cur nx;
@@ -758,7 +770,7 @@ struct TileWalker {
             const int64_t tf = tnn < te ? tnn : t_after;   // metadata two tiles ahead; at the end of the run: the caller's next run
             if (tf >= 0) meta.dma(tf, pad);
         }
-        multiply<BUF>(cur, q, q2, acc);
+        multiply<BUF>(cur, q, sv, acc);
         cur = nx;
         t = tn;
         tn = tnn;
@@ -1089,11 +1101,41 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     bool bok[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { bok[ks] = ks * 32 + 8 * g < a.Dpad; boff[ks] = bok[ks] ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u; }
-    const uint32_t idaddr[2] = {pad + (uint32_t)i * 4u, pad + 64u + (uint32_t)i * 4u};           // row ids of both halves
+    // WL (KS = 2, rows of one 128-byte line; r03): whole-line gathers, as in agnn_kernel - instruction q takes the eight rows of tile
+    // columns 8q .. 8q+7 (lane L: row slot L >> 3, the chunk that belongs at position L & 7) into block q, row-major; chunk c of row
+    // slot rho lies at position c ^ 2 (rho >> 1), which spreads the sixteen lanes of every ds_read_b128 lane group of the operand
+    // reads (row i of half sub = row slot i & 7 of block 2 sub + (i >> 3), chunk 4 ks + g) over the sixteen 16-byte bank slots.
+    // KS = 4 (256-byte rows): four rows per instruction, eight instructions, tile column tau in row slot tau & 3 of block tau >> 2,
+    // chunk c at position c ^ (4 (q & 3) + rho).  (KS = 3: the layout above, see agnn_kernel.)
+    constexpr bool WL = KS == 2 || KS == 4;
+    constexpr int RB = KS == 2 ? 128 : 256, RPI = 1024 / RB, NI = WL ? 32 / RPI : 2, CPR = RB / 16;
+    constexpr int NIDR = NI;                                                                      // row ids this lane reads per tile
+    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t {
+        if constexpr (KS == 2) return 2u * (rho >> 1);
+        else return 4u * (q & 3u) + rho;
+    };
+    uint32_t idaddr[NIDR];
+    if constexpr (WL) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) idaddr[q] = pad + (uint32_t)(RPI * q + lane / CPR) * 4u;
+    } else { idaddr[0] = pad + (uint32_t)i * 4u; idaddr[1] = pad + 64u + (uint32_t)i * 4u; }      // row ids of both halves
+    [[maybe_unused]] uint32_t choff[WL ? NI : 1];                                                 // WL: byte offset of my chunk inside the rows instruction q fetches
+    if constexpr (WL) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const uint32_t c = (uint32_t)(lane % CPR) ^ wl_sw((uint32_t)(lane / CPR), (uint32_t)q);
+            choff[q] = ((int)(c * 8u) < a.Dpad) ? c * 16u : 0u;
+        }
+    }
     uint32_t qaddr[1 + 2 * KS];                                                                   // edge offsets, then my landing slots
     qaddr[0] = pad + 192u + 16u * (uint32_t)g;
 #pragma unroll
-    for (int k = 0; k < 2 * KS; ++k) qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    for (int k = 0; k < 2 * KS; ++k) {
+        if constexpr (WL) {   // row i of half sub = tile column 16 sub + i
+            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS), tau = 16u * sub + (uint32_t)i, q = tau / RPI, rho = tau % RPI;
+            qaddr[1 + k] = ring + q * 1024u + rho * (uint32_t)RB + (((4u * ks + (uint32_t)g) ^ wl_sw(rho, q)) * 16u);
+        } else qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    }
     const uint32_t m4addr = pad + 128u + 16u * (uint32_t)g;
     // Output staging.  PMC (profiles/r01): scattering every result with its own 4-byte store costs
     // 7.6e7 L2 write requests per launch on top of the 1.25e8 gather reads, and the kernel runs at the
@@ -1138,6 +1180,20 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     };
 
     auto dma_b = [&](const uint32_t* cid, int bufbase) {
+        if constexpr (WL) {
+            if (a.big) {
+                const char* const xb = reinterpret_cast<const char*>(a.x16);
+#pragma unroll
+                for (int q = 0; q < NI; ++q)
+                    __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[q] * (uint64_t)(stride * 2) + choff[q]),
+                                                     (LDS_AS void*)(uintptr_t)(ring + bufbase + q * 1024), 16, 0, 0);
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+                __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + bufbase + q * 1024), 16, (int)cid[q], (int)choff[q], 0, 0, 0);
+            return;
+        }
         if (a.big) {
             const char* const xb = reinterpret_cast<const char*>(a.x16);
 #pragma unroll
@@ -1159,9 +1215,9 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     auto stage = [&](auto BUFC, Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
         constexpr int BUF = decltype(BUFC)::value;
         wait_vm0();
-        uint32_t cid[2];
+        uint32_t cid[NIDR];
         uintx4 m4n, q[1 + 2 * KS];
-        lds_ids_block<2>(idaddr, cid, m4addr, m4n);                // ids + masks of the next tile
+        lds_ids_block<NIDR>(idaddr, cid, m4addr, m4n);             // ids + masks of the next tile
         constexpr int NB = sddmm_nbuf(KS);
         lds_q_block<1 + 2 * KS, (NB == 2 ? BUF : 0) * BUF_BYTES>(qaddr, q);   // its edge offsets, and this tile's operands
         const bool more = tn < te;
@@ -1220,9 +1276,9 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     wait_vm0();
     Cur cur;
     {
-        uint32_t cid[2];
+        uint32_t cid[NIDR];
         uintx4 e4[1];
-        lds_ids_block<2>(idaddr, cid, m4addr, cur.m4);
+        lds_ids_block<NIDR>(idaddr, cid, m4addr, cur.m4);
         lds_q_block<1, 0>(qaddr, e4);
         cur.eb4 = e4[0];
         dma_b(cid, 0);
@@ -1322,23 +1378,6 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs 
 //   backward (BWD = true):  att = fl32(w * ef_saved) (edge values DMA'd one tile ahead),
 //            scores of dY are only reduced against the column ids: sum_e s[e] * (float)col(e).
 // ------------------------------------------------------------------------------------------
-// eight 4-byte LDS reads at per-lane addresses, retired before anything else is issued (agnn_kernel backward: the saved scores of
-// this lane's eight tile columns, picked out of its run by address instead of by a cascade of selects)
-__device__ __forceinline__ void lds_read8_b32(const uint32_t (&ad)[8], uint32_t (&v)[8]) {
-    asm volatile("ds_read_b32 %0, %8\n\t"
-                 "ds_read_b32 %1, %9\n\t"
-                 "ds_read_b32 %2, %10\n\t"
-                 "ds_read_b32 %3, %11\n\t"
-                 "ds_read_b32 %4, %12\n\t"
-                 "ds_read_b32 %5, %13\n\t"
-                 "ds_read_b32 %6, %14\n\t"
-                 "ds_read_b32 %7, %15\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-                 : "memory");
-}
-
 static constexpr int kAgnnXcds = 8;   // workgroup b runs on XCD b % 8
 struct AgnnArgs {
     const int64_t* wb_ptr;
@@ -1414,31 +1453,42 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     // 4 ks + g) fall into the sixteen 16-byte bank slots, and so do the eight rows x two chunks a 32-lane group of the transposed
     // reads of MFMA #2 addresses.  All of it is per-lane constants: the tile loop issues the same instructions as before, plus two
     // more row ids read from the pad.
-    constexpr bool WL = KS == 2;
-    constexpr int NV = WL ? 6 : 4;                                   // words read from the pad per tile: row ids, mask, edge offset
-    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t { return 4u * ((rho >> 1) & 1u) + ((0x1320u >> (4u * q)) & 3u); };
+    // KS = 4 (rows of two lines, D = 97 .. 128): the same with four 256-byte rows per instruction, eight instructions, tile column tau in
+    // row slot tau & 3 of block tau >> 2, sw = 8 ((q >> 1) & 1) + 2 rho.  (KS = 3 keeps the layout above: its 192-byte rows are
+    // gathered at a 256-byte pitch, which a row-major image of the tile would have to be sized for.)
+    constexpr bool WL = KS == 2 || KS == 4;
+    constexpr int RB = KS == 2 ? 128 : 256, RPI = 1024 / RB, NI = WL ? 32 / RPI : 2, CPR = RB / 16;   // row bytes, rows per instruction, instructions, chunks per row
+    constexpr int NV = WL ? NI + 2 : 4;                              // words read from the pad per tile: row ids, mask, edge offset
+    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t {
+        if constexpr (KS == 2) return 4u * ((rho >> 1) & 1u) + ((0x1320u >> (4u * q)) & 3u);
+        else return 8u * ((q >> 1) & 1u) + 2u * rho;
+    };
+    auto wl_pos = [&](uint32_t tau, uint32_t c) -> uint32_t {        // byte position of chunk c of tile column tau inside the tile image
+        const uint32_t q = tau / RPI, rho = tau % RPI;
+        return q * 1024u + rho * (uint32_t)RB + ((c ^ wl_sw(rho, q)) * 16u);
+    };
     const uint32_t pcol = (uint32_t)(8 * (i >> 2) + (i & 3));
     uint32_t idaddr[NV];
     if constexpr (WL) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) idaddr[q] = pad + (uint32_t)(8 * q + (lane >> 3)) * 4u;
+        for (int q = 0; q < NI; ++q) idaddr[q] = pad + (uint32_t)(RPI * q + lane / CPR) * 4u;
     } else { idaddr[0] = pad + pcol * 4u; idaddr[1] = pad + (pcol + 4u) * 4u; }
     idaddr[NV - 2] = pad + 128u + (uint32_t)i * 4u;
     idaddr[NV - 1] = pad + 192u + (uint32_t)i * 4u;
-    [[maybe_unused]] uint32_t choff[4] = {0u, 0u, 0u, 0u};         // WL: byte offset inside the row this lane fetches with instruction q
+    [[maybe_unused]] uint32_t choff[WL ? NI : 1];                   // WL: byte offset inside the row this lane fetches with instruction q
     if constexpr (WL) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t c = (uint32_t)(lane & 7) ^ wl_sw((uint32_t)(lane >> 3), (uint32_t)q);
+        for (int q = 0; q < NI; ++q) {
+            const uint32_t c = (uint32_t)(lane % CPR) ^ wl_sw((uint32_t)(lane / CPR), (uint32_t)q);
             choff[q] = ((int)(c * 8u) < a.Dpad) ? c * 16u : 0u;      // (a chunk past Dpad: chunk 0 instead - valid memory, multiplied by zeros)
         }
     }
     uint32_t qaddr[NQ];
 #pragma unroll
     for (int k = 0; k < 2 * KS; ++k) {
-        if constexpr (WL) {   // operand (sub, ks) of MFMA #1: row m = i of half sub, chunk 4 ks + g
-            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS), q = (uint32_t)(i >> 2), rho = 4u * sub + (uint32_t)(i & 3);
-            qaddr[k] = ring + q * 1024u + rho * 128u + (((4u * ks + (uint32_t)g) ^ wl_sw(rho, q)) * 16u);
+        if constexpr (WL) {   // operand (sub, ks) of MFMA #1: row m = i of half sub (tile column 8 (i >> 2) + 4 sub + (i & 3)), chunk 4 ks + g
+            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS);
+            qaddr[k] = ring + wl_pos(8u * (uint32_t)(i >> 2) + 4u * sub + (uint32_t)(i & 3), 4u * ks + (uint32_t)g);
         } else qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
     }
     [[maybe_unused]] const uint32_t vaddr0 = aux + (uint32_t)lane * 16u;   // backward: this lane's run of saved scores (second block: + 1024)
@@ -1449,9 +1499,8 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     for (int s = 0; s < NT; ++s)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if constexpr (WL) {   // row m = 4g + (i >> 2) of half h = row slot 4h + (i >> 2) of block g; features 16 s + 4 (i & 3) ..
-                const uint32_t rho = 4u * (uint32_t)h + (uint32_t)(i >> 2), c = 2u * (uint32_t)s + (uint32_t)((i & 3) >> 1);
-                raddr[s][h] = ring + (uint32_t)g * 1024u + rho * 128u + ((c ^ wl_sw(rho, (uint32_t)g)) * 16u) + 8u * (uint32_t)(i & 1);
+            if constexpr (WL) {   // row m = 4g + (i >> 2) of half h = tile column 8g + 4h + (i >> 2); features 16 s + 4 (i & 3) ..
+                raddr[s][h] = ring + wl_pos(8u * (uint32_t)g + 4u * (uint32_t)h + (uint32_t)(i >> 2), 2u * (uint32_t)s + (uint32_t)((i & 3) >> 1)) + 8u * (uint32_t)(i & 1);
             } else
                 raddr[s][h] = ring + (uint32_t)((h * KS + (s >> 1)) * 1024 + ((2 * (s & 1) + ((i & 3) >> 1)) * 16 + 4 * g + (i >> 2)) * 16 + 8 * (i & 1));
         }
@@ -1497,17 +1546,17 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             cnt = 0u; rstart = ~0u;
         };
         auto dma_b = [&](const uint32_t* cid) {
-            if constexpr (WL) {   // four instructions of eight whole rows each
+            if constexpr (WL) {   // NI instructions of RPI whole rows each
                 if (MAXW == 0 && a.big) {
                     const char* const xb = reinterpret_cast<const char*>(a.x16);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < NI; ++q)
                         __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[q] * (uint64_t)(stride * 2) + choff[q]),
                                                          (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, 0, 0);
                     return;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NI; ++q)
                     __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, (int)cid[q], (int)choff[q], 0, 0, 0);
                 return;
             }
@@ -2180,7 +2229,8 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
 //   D = 16 (7.4 MB)  per-window 1.13 / 1.43   sliced 1.06 / 1.28   range-major 1.19 / 1.59
 //   D = 32 (14.9 MB) per-window 1.46 / 1.65   sliced 1.20 / 1.38   range-major 1.26 / 1.65
 //   D = 64 (29.8 MB) per-window 1.74 / 1.77   sliced 1.53 / 1.60   range-major 1.45-1.48 / 1.78   (sixteen slices in two rounds 1.81 / 1.85)
-// so: sliced in both directions up to 16 MB; from there to 32 MB range-major forward and sliced backward.
+//   D = 128 (59.6 MB) per-window 3.50 / 3.57  range-major 2.76 / 2.99   (an eighth of the image is 7.4 MB: no slicing)
+// so: sliced in both directions up to 16 MB; from there to 32 MB range-major forward and sliced backward; to 64 MB range-major.
 // TCGNN_AGNN_SLICED (read per call: tests switch it): 0 per-window only, 1 the rule above, 2 sliced whenever possible, 16 two rounds.
 static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
 enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
@@ -2193,9 +2243,14 @@ static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_o
     if (image_is_big(plan->Nc, pitch)) return kAgnnPerWindow;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     if (knob >= 2) { *nslices_out = (knob == 16 && plan->nbuckets % 16 == 0) ? 16 : kAgnnXcds; return kAgnnSliced; }   // (forced)
-    if (!(x16_bytes > kBlockedMinBytes && x16_bytes <= (size_t)kAgnnXcds * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
+    if (!(x16_bytes > kBlockedMinBytes && x16_bytes <= 2 * (size_t)kAgnnXcds * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
           windows_balanced(plan) && !has_locality(plan))) return kAgnnPerWindow;
-    if (!bwd && x16_bytes > (size_t)kAgnnXcds * (kAgnnSliceBytes / 2)) return kAgnnRangeMajor;
+    if (x16_bytes > (size_t)kAgnnXcds * kAgnnSliceBytes) return kAgnnRangeMajor;                     // 32 - 64 MB: both directions
+    if (!bwd && x16_bytes > (size_t)kAgnnXcds * (kAgnnSliceBytes / 2)) return kAgnnRangeMajor;       // 16 - 32 MB: forward
+    // (the sliced walk wants every window's tiles spread evenly over the slices: workgroups are handed to the XCDs round-robin and
+    //  in order, so where a window has most of its tiles in one slice - the calibrated SBM graph: 22.5 % of the edges inside the
+    //  window's own community, near_frac 0.3 - the XCD of that slice holds the others up: backward 1.81 -> 2.40 ms there)
+    if (plan->near_frac > 0.2) return kAgnnPerWindow;
     *nslices_out = kAgnnXcds;
     return kAgnnSliced;
 }
@@ -3670,7 +3725,9 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
     hipError_t e;
     if (blocked) {
-        size_t range_bytes = 4 * kRangeTargetBytes;
+        // (r03, whole-line gathers: D = 64 1.26 / 1.24 ms at 4 / 8 MB ranges, 1.36 at 2 MB; D = 128 - an image of 60 MB - 2.33 at 2 MB,
+        //  2.58 at 4 MB, 3.5 per-window)
+        size_t range_bytes = x16_bytes > ((size_t)32 << 20) ? 2 * kRangeTargetBytes : 4 * kRangeTargetBytes;
         if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
         int nranges = 1;
         while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
