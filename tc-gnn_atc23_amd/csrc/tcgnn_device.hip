@@ -1649,11 +1649,23 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             // factor is 1.0 unless the exponent needs two steps, and multiplying by it is exact)
             [[maybe_unused]] uint32_t wpos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);   // forward: its staging slot
             uint32_t rb[8];
+            [[maybe_unused]] float scv[8];
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) scv[j] = S[j >> 2][j & 3] * inv_a;
+                if (__builtin_expect(two_step, 0)) {   // (kernel-uniform, almost never taken; the empty asm keeps it a branch - if-converted
+                                                       //  it costs a multiply and a select per column)
+                    asm volatile("; second scale factor");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) scv[j] *= inv_b;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);   // (one v_bfe_i32)
-                const float sraw = S[j >> 2][j & 3];
-                [[maybe_unused]] const float sc = (sraw * inv_a) * inv_b;
+                [[maybe_unused]] const float sraw = S[j >> 2][j & 3];
+                [[maybe_unused]] float sc = 0.f;
+                if constexpr (!BWD) sc = scv[j];
                 float att_s;
                 if constexpr (BWD) {
                     att_s = __uint_as_float(sv[j]) * c_val;                          // = fl32(w * ef) * 2^ka
@@ -1661,10 +1673,12 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                     dsum += __uint_as_float(__float_as_uint(sraw) & mk) * (float)(int32_t)cur.c[j >> 2][j & 3];
                 } else {
                     lds_write_b32(bitfield_select(mk, wpos, junk), sc);
-                    wpos -= mk << 2;
+                    asm("v_mad_i32_i24 %0, %1, -4, %0" : "+v"(wpos) : "v"(mk));           // wpos += 4 where the edge exists (mk = -1)
                     att_s = sc * c_val;                                              // = fl32(w * ef) * 2^ka
                 }
-                rb[j] = ((__float_as_uint(att_s) & mk) + 0x1000u) & 0xffffe000u;
+                // (+ half an ulp of the 10-bit mantissa; the 13 bits below it are cut by the round-toward-zero pack conversion itself -
+                //  in fp16's normal range exactly the bits `& 0xffffe000` would clear, below it a coarser cut toward zero of the same value)
+                rb[j] = (__float_as_uint(att_s) & mk) + 0x1000u;
             }
             half8 a16;
 #pragma unroll
@@ -2229,8 +2243,15 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
 //   D = 16 (7.4 MB)  per-window 1.13 / 1.43   sliced 1.06 / 1.28   range-major 1.19 / 1.59
 //   D = 32 (14.9 MB) per-window 1.46 / 1.65   sliced 1.20 / 1.38   range-major 1.26 / 1.65
 //   D = 64 (29.8 MB) per-window 1.74 / 1.77   sliced 1.53 / 1.60   range-major 1.45-1.48 / 1.78   (sixteen slices in two rounds 1.81 / 1.85)
-//   D = 128 (59.6 MB) per-window 3.50 / 3.57  range-major 2.76 / 2.99   (an eighth of the image is 7.4 MB: no slicing)
-// so: sliced in both directions up to 16 MB; from there to 32 MB range-major forward and sliced backward; to 64 MB range-major.
+//   D = 128 (59.6 MB) per-window 3.48 / 3.53  sliced 2.61-2.67 / 2.71-2.73   range-major 2.68-2.73 / 2.93-2.95   (slices of 7.4 MB: they do
+//                     not stay in a 4 MB L2, but an XCD that is asked for an eighth of the image still hits more often than one asked for all of it)
+// so: sliced in both directions up to 16 MB; from there to 64 MB range-major forward (within 2 % of sliced, no addends) and sliced backward.
+// What these walks are bound by is the memory system's throughput at their hit rate, not by what a wavefront has in flight nor by
+// its instruction count (r03, measured on the sliced walk at D = 64): a quarter fewer VALU instructions per tile (103 -> 71 in the
+// forward tile block) changed nothing; a second tile buffer with the gather running two tiles ahead (counted vmcnt, no extra
+// registers) moved forward 1.53 -> 1.53 and backward 1.60 -> 1.57 and was taken out again; four wavefronts per SIMD instead of
+// three (forward kernel squeezed from 130 to 128 registers, 12 bytes of scratch) 1.53 -> 1.43-1.45 sliced but 1.73 -> 1.79-1.87 per-window
+// (more wavefronts thrash the L2 harder) - level with range-major's 1.45-1.48, so not kept either.
 // TCGNN_AGNN_SLICED (read per call: tests switch it): 0 per-window only, 1 the rule above, 2 sliced whenever possible, 16 two rounds.
 static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
 enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
@@ -2245,7 +2266,7 @@ static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_o
     if (knob >= 2) { *nslices_out = (knob == 16 && plan->nbuckets % 16 == 0) ? 16 : kAgnnXcds; return kAgnnSliced; }   // (forced)
     if (!(x16_bytes > kBlockedMinBytes && x16_bytes <= 2 * (size_t)kAgnnXcds * kAgnnSliceBytes && plan->nw_eff >= 8 * plan->num_cus &&
           windows_balanced(plan) && !has_locality(plan))) return kAgnnPerWindow;
-    if (x16_bytes > (size_t)kAgnnXcds * kAgnnSliceBytes) return kAgnnRangeMajor;                     // 32 - 64 MB: both directions
+    if (x16_bytes > (size_t)kAgnnXcds * kAgnnSliceBytes && !bwd) return kAgnnRangeMajor;             // 32 - 64 MB: forward
     if (!bwd && x16_bytes > (size_t)kAgnnXcds * (kAgnnSliceBytes / 2)) return kAgnnRangeMajor;       // 16 - 32 MB: forward
     // (the sliced walk wants every window's tiles spread evenly over the slices: workgroups are handed to the XCDs round-robin and
     //  in order, so where a window has most of its tiles in one slice - the calibrated SBM graph: 22.5 % of the edges inside the
