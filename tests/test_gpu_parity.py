@@ -589,7 +589,7 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
             assert np.abs(gemm["0"][0].cpu().numpy() - Z.cpu().numpy()).max() <= TIGHT * scale
 
 
-@pytest.mark.parametrize("D", [16, 41, 64])
+@pytest.mark.parametrize("D", [16, 41, 64, 96, 128])   # (128: what the backward pass takes on the Reddit shape since r03; 96: the old row layout)
 def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatch):
     """r03: the XCD-sliced walk of the fused kernel (workgroup b gathers only rows of column slice b % 8, so an XCD's L2 holds the
     slice it is asked for; a wavefront = one window's tiles inside the slice; the slices' addends of Y summed in slice order by
