@@ -1399,6 +1399,7 @@ struct AgnnArgs {
     int32_t nbuckets, gsel, nranges, nw, ngroups;
     int32_t big;               // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
     int32_t nslices;           // > 0 (MAXW = 0 only): the XCD-sliced walk, see agnn_kernel
+    int32_t valonly;           // backward kernel as an edge-valued SpMM (tcgnn_spmm_val on the sliced walk): Y = sum ef[e] X[col(e)], no scores, w = 1
 };
 
 static constexpr int agnn_wave_lds(int ks, bool bwd) {
@@ -1410,7 +1411,8 @@ static constexpr int agnn_wave_lds(int ks, bool bwd) {
 //           ranges in step, as spmm_blocked_kernel does, so the gathered rows stay L2-resident.
 template <int NT, int WAVES, bool BWD, int MAXW>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
-    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    const bool valonly = BWD && a.valonly != 0;   // (kernel-uniform)
+    if (valonly ? range_is_wide_val(a.hdr) : range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = (NT + 1) / 2;
     constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
     const int kx = scale_exp_from_bits(a.hdr[0]);
     const bool two_step = kx > 63 || kx < -63;                     // score = acc * 2^(-2kx), in two factors if needed
     const float inv_a = two_step ? pow2f(-kx) : pow2f(-2 * kx), inv_b = two_step ? pow2f(-kx) : 1.0f;
-    const float wv = a.w[0];
+    const float wv = a.w ? a.w[0] : 1.0f;
     // power-of-two scale of the edge weights att = w * ef.  forward: |ef| <= Dpad * max|x|^2 (no pass over E);
     // backward: the recorded max |ef|.  Rounding to a 10-bit mantissa does not depend on the scale.
     float att_bound;
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
             uint32_t v[NV];
             uintx4 q[NQ];
             lds_ids_block<NV>(idaddr, v, qaddr[0], q[0]);         // next tile: its row ids for my lane, my row's mask and edge offset; + operand 0
-            lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);             // the other operands
+            if (!valonly) lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);   // the other operands (values only: no scores, nothing reads them)
             // backward: the saved score of tile column j of my eight is word (edges of row i left of it in my run) of the run the
             // DMA fetched - read by ADDRESS (r03; a cascade of selects over eight registers cost ten VALU instructions per column
             // in a loop that is VALU-bound: 265 per tile, SQ_INSTS_VALU of profiles/r02).  Lanes without the edge read a
@@ -1635,7 +1637,7 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 S[sub] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (__any((cur.m & halfbits[sub]) != 0u)) {
+                if (!valonly && __any((cur.m & halfbits[sub]) != 0u)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         S[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, q[sub * KS + ks]), af[ks], S[sub], 0, 0, 0);
@@ -1669,8 +1671,6 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 float att_s;
                 if constexpr (BWD) {
                     att_s = __uint_as_float(sv[j]) * c_val;                          // = fl32(w * ef) * 2^ka
-                    // (the raw accumulator: its power-of-two scale is applied once, to the workgroup's sum)
-                    dsum += __uint_as_float(__float_as_uint(sraw) & mk) * (float)(int32_t)cur.c[j >> 2][j & 3];
                 } else {
                     lds_write_b32(bitfield_select(mk, wpos, junk), sc);
                     asm("v_mad_i32_i24 %0, %1, -4, %0" : "+v"(wpos) : "v"(mk));           // wpos += 4 where the edge exists (mk = -1)
@@ -1679,6 +1679,15 @@ __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(con
                 // (+ half an ulp of the 10-bit mantissa; the 13 bits below it are cut by the round-toward-zero pack conversion itself -
                 //  in fp16's normal range exactly the bits `& 0xffffe000` would clear, below it a coarser cut toward zero of the same value)
                 rb[j] = (__float_as_uint(att_s) & mk) + 0x1000u;
+            }
+            if constexpr (BWD) {
+                if (!valonly) {   // sum_e s[e] * col(e) (the raw accumulators: their power-of-two scale is applied once, to the workgroup's sum)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);
+                        dsum += __uint_as_float(__float_as_uint(S[j >> 2][j & 3]) & mk) * (float)(int32_t)cur.c[j >> 2][j & 3];
+                    }
+                }
             }
             half8 a16;
 #pragma unroll
@@ -3011,6 +3020,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
 // 128-column chunks.  Wider matrices go through the gather walks as independent column blocks (ld = the full row length).
 static constexpr int kMaxGatherBlockDims = 4096;
 
+static bool agnn_supported(const tcgnn_plan* plan, int32_t D);
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
                     void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr,
                     int64_t ld = 0, bool block_of_wider = false, const float* d_W = nullptr, int32_t D_out = 0) {
@@ -3144,6 +3154,31 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     };
+    // ---- edge values on the fused AGNN kernel's XCD-sliced walk (r03).  Where the fused pair's backward pass takes that walk (graphs
+    //      without locality of their own, windows alike, an fp16 image of 16 - 64 MB: agnn_walk) the edge-valued SpMM is the same
+    //      gather with less to do per tile, so it runs as that kernel with the score half switched off (AgnnArgs::valonly: w = 1,
+    //      ef = the caller's values, their abs-max from this call's header): 76 % L2 hits and 5.8 GB of fabric reads instead of the
+    //      per-window walk's 31 % and 12.2 GB on the Reddit shape at D = 64.  Same operand rounding and scales; the sums run in slice order.
+    if (d_val && !d_staged && !block_of_wider && !d_gate && !relu && mode == 0 && dpad > 32 && dpad <= kMaxChunkDims && agnn_supported(plan, D)) {
+        int ns = 0;
+        const size_t need = workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D);
+        if (agnn_walk(plan, D, true, &ns) == kAgnnSliced && ns > 0 && ws_bytes >= need) {
+            double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D));
+            float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
+            AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, nullptr, const_cast<float*>(d_val), const_cast<uint32_t*>(hdr) + 1, ypart, partial,
+                       plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, plan->nbuckets / ns, 0, plan->nw_eff, 0,
+                       image_is_big(plan->Nc, pitch), ns, 1};
+            {
+                KernelTimer timer(plan, stream, "agnn_kernel (XCD-sliced, values only) + agnn_slice_sum_kernel");
+                HIP_TRY((launch_agnn<4, true, 0>(dpad / 16, a, ns * ((plan->nw_eff + 3) / 4), stream)));
+                const int64_t nsum = std::min<int64_t>(plan->N, (int64_t)plan->nw_eff * kWinRows) * D;   // (rows beyond the windows were zeroed above)
+                const unsigned sg = (unsigned)std::min<int64_t>(2048, (nsum / 4 + 255) / 256 + 1);
+                hipLaunchKernelGGL(agnn_slice_sum_kernel, dim3(sg), dim3(256), 0, stream, ypart, d_Y, nsum, (int64_t)plan->N * D, ns);
+                HIP_TRY(hipGetLastError());
+            }
+            return wide_fallback();
+        }
+    }
     if (lds) {
         int total_chunks = 0;
         for (int i = 0; i < npass; ++i) total_chunks += passes[i].nchunks;
@@ -3273,7 +3308,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
                plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
-               image_is_big(plan->Nc, pitch), 0};
+               image_is_big(plan->Nc, pitch), 0, 0};
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));

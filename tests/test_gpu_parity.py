@@ -607,8 +607,15 @@ def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatc
     tH, tdY = to_dev(dev, H, dY)
     tw = torch.tensor([-1.3], device=dev)
     out = {}
+    val = rng.standard_normal(nnz).astype(np.float32)
+    tval = to_dev(dev, val)[0].view(1, -1).contiguous()
+    yv = {}
     for sl in ("0", "2", "16"):
         monkeypatch.setenv("TCGNN_AGNN_SLICED", sl)
+        # the edge-valued SpMM takes the sliced walk too where the fused backward pass does (wider than 32 columns): the fused
+        # kernel with its score half switched off
+        yv[sl] = T.forward_AGNN(tH, trp, tcol, tval, tbp, te2c, te2r)[0].cpu().numpy()
+        assert ("values only" in T.last_kernel(*meta)) == (sl != "0" and D > 32), (sl, D, T.last_kernel(*meta))
         Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
         kf = T.last_kernel(*meta)
         G, dw = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
@@ -623,6 +630,11 @@ def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatc
     refG = O.spmm_val(dY, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
     d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
     want = float((d_att * col).sum()); term_scale = float((np.abs(d_att) * col).sum()) + 1.0
+    V64, absV = O.spmm_f64(H, rp, col, val)
+    refV = O.spmm_val(H, rp, col, val, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    for sl in ("0", "2", "16"):
+        assert_parity(yv[sl], refV, V64, absV, "forward_AGNN sliced %s" % sl)
+        assert np.abs(yv[sl] - yv["0"]).max() <= TIGHT * (absV.max() + 1.0)
     for sl in ("2", "16"):
         Y, ef, efm, G, dw = out[sl]
         assert np.array_equal(ef, out["0"][1]) and efm == out["0"][2]
