@@ -1054,7 +1054,9 @@ struct SddmmArgs {
     const uint32_t* bptr;       // range-blocked walk (nranges > 0)
     int32_t nbuckets, gsel, nranges, nw;
     int32_t big;                // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
+    int32_t xcd;                // range-major walk with XCD affinity: workgroup b (on XCD b % 8) takes the ranges r = b % 8, b % 8 + 8, ... only
 };
+static constexpr int kXcdCount = 8;   // workgroups are dealt to the XCDs round-robin in launch order
 
 // LDS of one SDDMM wavefront: two operand buffers, the metadata pad, the output staging area
 // (16 rows x kSddmmStageCap floats) and 256 bytes of junk slots for lanes that have nothing to stage.
@@ -1295,6 +1297,22 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
     if constexpr (BLOCKED) {
         // persistent wavefronts take (column range, window) items in range-major order: at any moment
         // the whole chip gathers from one or two ranges of X16, which stay L2-resident
+        if (a.xcd) {
+            // XCD affinity (r03, after the whole-line gathers made an L2 hit worth twice a miss): the workgroups of XCD x gather from
+            // the ranges x, x + 8, ... only, one after the other - that XCD's L2 is asked for an eighth of the image, a range or two of
+            // it at a time, instead of every range every other XCD is walking as well.  Every edge lies in exactly one range, so
+            // nothing is added up afterwards and the scores are bit for bit those of the other walks.
+            const int x = (int)(blockIdx.x % (unsigned)kXcdCount);
+            const int64_t items_x = (int64_t)(a.nranges / kXcdCount) * a.nw, lstride = (int64_t)(gridDim.x / (unsigned)kXcdCount) * WAVES;
+            for (int64_t q = (int64_t)(blockIdx.x / (unsigned)kXcdCount) * WAVES + wave; q < items_x; q += lstride) {
+                const int rr = (int)(q / a.nw), r = x + kXcdCount * rr;
+                const int w = __builtin_amdgcn_readfirstlane(a.order[q - (int64_t)rr * a.nw]);
+                const int64_t tb = a.wb_ptr[w];
+                const uint32_t* bp = a.bptr + (int64_t)w * (a.nbuckets + 1);
+                run(w, tb + bp[r * a.gsel], tb + bp[(r + 1) * a.gsel], 1);
+            }
+            return;
+        }
         const int64_t items = (int64_t)a.nranges * a.nw;
         for (int64_t q = (int64_t)blockIdx.x * WAVES + wave; q < items; q += (int64_t)gridDim.x * WAVES) {
             const int r = (int)(q / a.nw);
@@ -3771,7 +3789,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const Guard gsd = guard_sddmm(D);
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch)};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream, ks <= 4 ? "sddmm_kernel" : "sddmm_wide_kernel");
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
@@ -3782,7 +3800,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     hipError_t e;
     if (blocked) {
         // (r03, whole-line gathers: D = 64 1.26 / 1.24 ms at 4 / 8 MB ranges, 1.36 at 2 MB; D = 128 - an image of 60 MB - 2.33 at 2 MB,
-        //  2.58 at 4 MB, 3.5 per-window)
+        //  2.58 at 4 MB, 3.5 per-window; with XCD affinity 2.01 at 2 or 4 MB)
         size_t range_bytes = x16_bytes > ((size_t)32 << 20) ? 2 * kRangeTargetBytes : 4 * kRangeTargetBytes;
         if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
         int nranges = 1;
@@ -3792,7 +3810,11 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         const int lds_wg = 4 * sddmm_wave_lds(ks);
         const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds_wg));
         const int64_t items = (int64_t)nranges * plan->nw_eff;
-        const int nwg = (int)std::min<int64_t>((items + 3) / 4, (int64_t)plan->num_cus * per_cu);
+        int nwg = (int)std::min<int64_t>((items + 3) / 4, (int64_t)plan->num_cus * per_cu);
+        // XCD affinity (sddmm_kernel; TCGNN_SDDMM_XCD=0 switches it off, read per call: tests compare the two).  Reddit shape:
+        // D = 128 2.32 -> 2.01 ms, D = 64 1.36 -> 1.33, D = 16 / 32 -1 .. -2.5 %; before the whole-line gathers it returned nothing.
+        const char* const xenv = getenv("TCGNN_SDDMM_XCD");
+        if ((!xenv || atoi(xenv)) && nranges % kXcdCount == 0 && nwg >= kXcdCount) { a.xcd = 1; nwg -= nwg % kXcdCount; }
         e = launch_sddmm_ks<4, true>(ks, a, nwg, stream);
     } else {
         e = plan->waves == 4 ? launch_sddmm_ks<4, false>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1, false>(ks, a, plan->nw_eff, stream);

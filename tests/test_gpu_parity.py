@@ -466,6 +466,41 @@ def test_locality_statistic_of_the_numbering(dev, T, capfd, monkeypatch):
     assert 8 <= seen["uniform"] <= 20 and seen["sbm"] >= 75, seen
 
 
+@pytest.mark.parametrize("D", [16, 64, 128])
+def test_sddmm_range_major_walk_with_xcd_affinity_gives_the_same_scores(dev, T, D, monkeypatch):
+    """r03: the range-major SDDMM with XCD affinity (workgroup b takes the column ranges b % 8, b % 8 + 8, ... only, so an XCD's
+    L2 is asked for an eighth of the image).  Every edge lies in exactly one range: the scores are bit for bit those of the
+    per-window walk and of the range-major walk without affinity.  Forced here with small ranges (TCGNN_RANGE_KB) on a graph the
+    oracle can handle, N % 16 != 0, so that there are 8, 16 and more ranges."""
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(70003, 80, seed=23)
+    n = len(rp) - 1
+    (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    assert T.plan_info(*meta)["column_buckets"] % 16 == 0
+    X = (np.random.default_rng(D).standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
+    tX = to_dev(dev, X)[0]
+    ref = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    ef64, efabs = O.sddmm_f64(X, rp, col)
+    out = {}
+    try:
+        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+        out["per-window"] = T.forward_ef(tX, *meta)[0]
+        c.check(c.lib.tcgnn_set_spmm_mode(2), "tcgnn_set_spmm_mode")
+        image_kb = (n + 1) * max(32, 1 << int(np.ceil(np.log2(2 * ((D + 15) // 16 * 16))))) // 1024
+        for xcd in ("0", "1"):
+            for parts in (8, 16, 64):
+                monkeypatch.setenv("TCGNN_SDDMM_XCD", xcd)
+                monkeypatch.setenv("TCGNN_RANGE_KB", str(max(1, image_kb // parts)))
+                out[(xcd, parts)] = T.forward_ef(tX, *meta)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    base = out["per-window"]
+    assert_parity(base.cpu().numpy(), ref, ef64, efabs, "sddmm per-window")
+    for k, v in out.items():
+        assert torch.equal(v, base), k
+
+
 @pytest.mark.parametrize("hot", [None, 1800])
 @pytest.mark.parametrize("D", [16, 48, 64, 128])
 def test_lds_resident_walk_splits_hub_windows_over_wavefronts(dev, T, D, hot, capfd, monkeypatch):
