@@ -1908,14 +1908,22 @@ __global__ __launch_bounds__(256) void agnn_slice_sum_kernel(const float* __rest
     }
 }
 
-// partial[0..n) -> out[0], fixed order
-__global__ void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out) {
-    __shared__ double sh[256];
+// partial[0..n) -> out[0], fixed order.  One workgroup of 1024, four independent loads per thread and step: the sliced walk leaves
+// 29 k partials on the Reddit shape, and 256 threads taking one dependent load per step spent 47 us on them (a memory round trip
+// per step) - 2 x 47 us of an AGNN epoch.
+static constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out) {
+    __shared__ double sh[kReduceThreads];
     double s = 0.0;
-    for (int k = threadIdx.x; k < n; k += 256) s += partial[k];
+    int k = (int)threadIdx.x;
+    for (; k + 3 * kReduceThreads < n; k += 4 * kReduceThreads) {
+        const double a = partial[k], b = partial[k + kReduceThreads], c = partial[k + 2 * kReduceThreads], d = partial[k + 3 * kReduceThreads];
+        s += (a + b) + (c + d);
+    }
+    for (; k < n; k += kReduceThreads) s += partial[k];
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
+    for (int o = kReduceThreads / 2; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
@@ -3378,7 +3386,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         HIP_TRY(hipGetLastError());
     }
     if (bwd) {
-        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, nwg, d_dw);
+        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw);
         HIP_TRY(hipGetLastError());
     }
     return TCGNN_OK;
@@ -3814,7 +3822,12 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         // XCD affinity (sddmm_kernel; TCGNN_SDDMM_XCD=0 switches it off, read per call: tests compare the two).  Reddit shape:
         // D = 128 2.32 -> 2.01 ms, D = 64 1.36 -> 1.33, D = 16 / 32 -1 .. -2.5 %; before the whole-line gathers it returned nothing.
         const char* const xenv = getenv("TCGNN_SDDMM_XCD");
-        if ((!xenv || atoi(xenv)) && nranges % kXcdCount == 0 && nwg >= kXcdCount) { a.xcd = 1; nwg -= nwg % kXcdCount; }
+        // (like the fused kernel's sliced walk it wants every window's tiles spread evenly over the ranges: on the calibrated SBM graph -
+        //  22.5 % of a window's edges inside its own community, near_frac 0.3 - the XCD that owns a window's community holds the others
+        //  up, 1.43 -> 2.11 ms at D = 64, where an XCD has ONE range; with four ranges per XCD, spread over the graph, the load evens
+        //  out again: D = 128 2.48 -> 2.25 ms there; TCGNN_SDDMM_XCD=2 forces it)
+        const int xknob = xenv ? atoi(xenv) : 1;
+        if (xknob && (xknob >= 2 || plan->near_frac <= 0.2 || nranges >= 4 * kXcdCount) && nranges % kXcdCount == 0 && nwg >= kXcdCount) { a.xcd = 1; nwg -= nwg % kXcdCount; }
         e = launch_sddmm_ks<4, true>(ks, a, nwg, stream);
     } else {
         e = plan->waves == 4 ? launch_sddmm_ks<4, false>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1, false>(ks, a, plan->nw_eff, stream);

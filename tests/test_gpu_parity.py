@@ -490,7 +490,7 @@ def test_sddmm_range_major_walk_with_xcd_affinity_gives_the_same_scores(dev, T, 
         image_kb = (n + 1) * max(32, 1 << int(np.ceil(np.log2(2 * ((D + 15) // 16 * 16))))) // 1024
         for xcd in ("0", "1"):
             for parts in (8, 16, 64):
-                monkeypatch.setenv("TCGNN_SDDMM_XCD", xcd)
+                monkeypatch.setenv("TCGNN_SDDMM_XCD", "2" if xcd == "1" else "0")
                 monkeypatch.setenv("TCGNN_RANGE_KB", str(max(1, image_kb // parts)))
                 out[(xcd, parts)] = T.forward_ef(tX, *meta)[0]
     finally:

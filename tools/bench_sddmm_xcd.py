@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""SDDMM kernel time on the Reddit-shaped graph at D = 64 / 16 / 32 / 128 under the environment given (TCGNN_SDDMM_XCD, TCGNN_RANGE_KB), with a checksum of the scores."""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")): sys.path.insert(0, p)
 import numpy as np, torch
 import TCGNN, tcgnn_graph as G
