@@ -31,3 +31,13 @@ def test_audit_script_detects_a_planted_violation(tmp_path):
     s.write_text("_Zok:\n;;#ASMSTART\n\tds_read_b32 v3, v1\n\ts_waitcnt lgkmcnt(0)\n;;#ASMEND\n\tv_mov_b32_e32 v2, v3\n\ts_endpgm\n")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_hidden_loads.py"), str(s)], capture_output=True, text=True)
     assert r.returncode == 0
+
+
+def test_library_is_not_older_than_its_sources():
+    """The in-tree libtcgnn_hip.so is what travels to the GPU box, and tcgnn_capi.build_id() - the key of profiles/ - hashes the
+    SOURCES: a library left over from an earlier build (a failed `make` behind an edit) would run under the wrong id unnoticed.
+    `make -q` says whether anything would be rebuilt."""
+    lib = os.path.join(ROOT, "tc-gnn_atc23_amd", "lib", "libtcgnn_hip.so")
+    assert os.path.exists(lib), "libtcgnn_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tc-gnn_atc23_amd", "csrc"), "-q", "all"], capture_output=True, text=True)
+    assert r.returncode == 0, "libtcgnn_hip.so is older than its sources: run make -C tc-gnn_atc23_amd/csrc"
