@@ -109,7 +109,7 @@ def sddmm_bytes(n, e, d):
     return 4 * (n + 1) + 8 * e + 4 * n * d
 
 
-def load_profile(kernel, workload, val=None):
+def load_profile(kernel, workload, val=None, bwd=None):
     """PMC numbers of (kernel, workload) from the newest profiles/r*/traffic.json - ONLY if that file was collected from the
     sources this process runs (tcgnn_capi.build_id(); tools/collect_profiles.py writes it).  -> (row or None, note).
     A stale or missing profile yields None and says why: the line never quotes counters of another kernel version."""
@@ -134,6 +134,10 @@ def load_profile(kernel, workload, val=None):
         # spmm_kernel / spmm_blocked_kernel exist with and without edge values (last template argument)
         if val is not None and name.split("<")[0] in ("spmm_kernel", "spmm_blocked_kernel") and name.rstrip(">").split(",")[-1].strip() != ("true" if val else "false"):
             continue
+        # agnn_kernel<NT, WAVES, BWD, MAXW>: forward and backward are different instantiations (the edge-valued SpMM on the sliced walk
+        # runs the backward one with its score half off: the collector's row averages over both uses)
+        if bwd is not None and name.split("<")[0] == "agnn_kernel" and name.rstrip(">").split(",")[2].strip() != ("true" if bwd else "false"):
+            continue
         return row, "%s (build %s)" % (rel, bid)
     return None, "%s has no row for %s on %s" % (rel, kernel, workload)
 
@@ -141,16 +145,19 @@ def load_profile(kernel, workload, val=None):
 MFMA_PEAK = 2.5e15   # fp16 dense, MI355X_MICROARCH.md
 
 
-def profile_fields(kernel, workload, flops, kernel_ms, val=False):
+def profile_fields(kernel, workload, flops, kernel_ms, val=False, bwd=None):
     """traffic + MFMA figures for one kernel on one dataset: PMC-measured where a fresh profile exists, live otherwise.
     A leg that runs two kernels ("spmm_lds_kernel + spmm_kernel (cold remainder)") reports the sum of their traffic and the
     MFMA figures of the first."""
     names = [k.split("(")[0].strip() for k in kernel.split(" + ")]
-    row, note = load_profile(names[0], workload, val)
+    row, note = load_profile(names[0], workload, val, bwd)
     if row and len(names) > 1:
         row = dict(row)
         for extra_name in names[1:]:
-            r2, _ = load_profile(extra_name, workload, val)
+            r2, _ = load_profile(extra_name, workload, val, bwd)
+            if r2 is None and extra_name == "agnn_slice_sum_kernel":   # (the pass that adds the sliced walk's addends: not profiled, ~1 GB of streaming)
+                note += "; without agnn_slice_sum_kernel"
+                continue
             if r2 is None:
                 row, note = None, note + "; no row for " + extra_name
                 break
@@ -403,7 +410,7 @@ def single_gpu(args):
         if "spmm_val" in ops:
             att_ = torch.randn(1, E_, device=dev, generator=g)
             leg = timed_leg(m_, E_, lambda: TCGNN.forward_AGNN(X_, rp_, col_, att_, bp_, e2c_, e2r_), spmm_bytes(n_, E_, d) + 4 * E_, reps=10)
-            leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"], val=True))
+            leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"], val=True, bwd=True))
             row["spmm_val"] = leg
             del att_
         if "sddmm" in ops:
@@ -416,9 +423,11 @@ def single_gpu(args):
             _, ef_, efm_ = TCGNN.agnn_fused_forward(Xs_, rp_, col_, w_, bp_, e2c_, e2r_)
             pb = sddmm_bytes(n_, E_, d) + 4 * n_ * d
             leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_forward(Xs_, rp_, col_, w_, bp_, e2c_, e2r_), pb, reps=10)
-            leg.update(profile_fields(leg["kernel"], wl, 4.0 * E_ * d, leg["kernel_ms"]))
+            leg.update(profile_fields(leg["kernel"], wl, 4.0 * E_ * d, leg["kernel_ms"], bwd=False))
             row["agnn_fused_fwd"] = leg
-            row["agnn_fused_bwd"] = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_backward(Xs_, rp_, col_, w_, ef_, efm_, bp_, e2c_, e2r_), pb, reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_backward(Xs_, rp_, col_, w_, ef_, efm_, bp_, e2c_, e2r_), pb, reps=10)
+            leg.update(profile_fields(leg["kernel"], wl, 4.0 * E_ * d, leg["kernel_ms"], bwd=True))
+            row["agnn_fused_bwd"] = leg
             del ef_, efm_, Xs_
         if "agnn_epoch" in ops or "gcn_epoch" in ops:
             _, _, in_dim_, classes_ = G.SHAPES[shape]
