@@ -211,6 +211,53 @@ def test_shard_whose_feature_matrix_needs_64_bit_addresses():
     ops.close()
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_row_shard_on_the_xcd_sliced_and_xcd_affine_walks(D, monkeypatch):
+    """r03: a rank's rectangular shard (A is rows x num_cols, its rows sit at row_offset inside X) on the walks that slice the COLUMNS
+    by XCD - the edge-valued SpMM on the fused kernel's sliced walk (score half off) and the range-major SDDMM with XCD affinity -
+    forced here, against float64 gathers and against the same shard on the per-window walks."""
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    dev = torch.device("cuda:0")
+    rows, H, deg = 40_003, 40_003, 40
+    layout = S.ShardLayout([0, H, 2 * H])
+    num_cols = layout.num_cols
+    rng = np.random.default_rng(5)
+    cols = np.sort(rng.integers(0, num_cols, size=(rows, deg)), axis=1)
+    keep = np.ones_like(cols, dtype=bool); keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    lrp = np.zeros(rows + 1, np.int32); lrp[1:] = np.cumsum(keep.sum(1))
+    lcol = cols[keep].astype(np.int32)
+    ops = S.HipShardOps(lrp, lcol, layout, 1, dev)      # rank 1: row_off = H
+    g = torch.Generator(device=dev).manual_seed(D)
+    X = torch.randn(num_cols, D, device=dev, generator=g)
+    att = torch.randn(lcol.size, device=dev, generator=g)
+    tcol = torch.from_numpy(lcol).to(dev).long()
+    erow = torch.repeat_interleave(torch.arange(rows, device=dev), torch.from_numpy(np.diff(lrp)).to(dev).long())
+    Xn = X[tcol].double()
+    refv = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, att.double()[:, None] * Xn)
+    scalev = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, (att.double()[:, None] * Xn).abs()) + 1.0
+    Xr = X[ops.row_off + erow].double()                                 # (blocks are padded to a common height: row_off = rank * layout.H)
+    refe = (Xr * Xn).sum(1); scalee = (Xr * Xn).abs().sum(1) + 1.0
+    name = lambda: c.lib.tcgnn_plan_last_kernel(ops.plan).decode()
+    try:
+        monkeypatch.setenv("TCGNN_AGNN_SLICED", "0"); monkeypatch.setenv("TCGNN_SDDMM_XCD", "0")
+        yv0, ef0 = ops.spmm_val(X, att), ops.sddmm(X)
+        monkeypatch.setenv("TCGNN_AGNN_SLICED", "2")
+        yv1 = ops.spmm_val(X, att); kv = name()
+        c.check(c.lib.tcgnn_set_spmm_mode(2), "tcgnn_set_spmm_mode")
+        monkeypatch.setenv("TCGNN_SDDMM_XCD", "2"); monkeypatch.setenv("TCGNN_RANGE_KB", "256")
+        ef1 = ops.sddmm(X)
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    assert "values only" in kv, kv
+    for y in (yv0, yv1):
+        assert ((y.double() - refv).abs() / scalev).max().item() <= 2.0 ** -9
+    assert ((yv1 - yv0).abs().double() / scalev).max().item() <= 1e-5
+    assert ((ef0.double() - refe).abs() / scalee).max().item() <= 2.0 ** -9
+    assert torch.equal(ef0, ef1)
+    ops.close()
+
+
 def _rccl_worker(rank, world, port, out_dir):
     """World of ONE under backend "nccl" (= RCCL): every collective of the N-rank step executes - all_gather_into_tensor of the
     fp32 row blocks, the one-word int32 all_reduce(MAX), all_gather_into_tensor of the fp16 image slices into the strided view,
