@@ -37,6 +37,7 @@ cpu_baseline: the row-parallel CSR gather-add (the DGL-CPU-style aggregation) of
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -347,7 +348,7 @@ def single_gpu(args):
         # measured staging / launch share of a step: what a cold-start average would report
         "value_all_launches": round(E / ((float(np.mean(kernel_ms_all)) + (ms_per_step - k_mean)) * 1e-3) / 1e9, 3) if kernel_ms_all else None,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 operands (TF32-equivalent rounding), f32 accumulate, f32 I/O", "data": data,
+        "dtype": "f16 x f16 -> f32 (MFMA), f32 I/O", "data": data,
         "config": {"workload": workload, "graph": "seeded uniform symmetric, canonical CSR" if data == "synthetic" else data, "tc_blocks_16x8": info["tc_blocks"],
                    "reddit_real_tc_blocks_16x8": 13566510, "wide_blocks_16x32": info["wide_blocks"],
                    "waves_per_window": info["waves_per_window"], "lds_column_ranges": info.get("lds_ranges", 0), "parallelism": "1 GPU"},
@@ -493,6 +494,17 @@ def single_gpu(args):
                 extra["%s_ms_per_epoch_hip_graph" % model] = round(rg["train_ms"], 3)
             except Exception as exc:
                 extra["%s_ms_per_epoch_hip_graph" % model] = "failed: %s" % str(exc)[:120]
+        # ---- the north star's grid, "hidden=16/64/128": the same two epochs at the other two widths (1_bench_gcn.py:6,33-38 and
+        #      1_bench_agnn.py:29-41 sweep --hidden the same way)
+        for h in (16, 128):
+            if h == D:
+                continue
+            for model in ("gcn", "agnn"):
+                try:
+                    r = H.time_training(model, meta, feats, labels, in_dim, h, classes, 2, max(3, args.epochs // 2), seed=args.seed)
+                    extra["%s_h%d_ms_per_epoch" % (model, h)] = round(r["train_ms"], 3)
+                except Exception as exc:
+                    extra["%s_h%d_ms_per_epoch" % (model, h)] = "failed: %s" % str(exc)[:120]
         del feats
 
     # ---- per-dataset list (north star: "MFMA utilisation and HBM GB/s ... on each dataset"): the headline graph, the same shape
@@ -510,7 +522,7 @@ def single_gpu(args):
         more = ((args.shape, "sbm_hubs", D, every), (args.shape, "sbm_shuffled", D, every), (args.shape, "sbm_shuffled+reorder", D, every + ("gcn_epoch", "agnn_epoch"))) if args.all_generators else ()
         for shape, gen, d, ops in ((args.shape, "sbm_reddit", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")),
                                    (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")), *more,
-                                   ("ogbn-products", "uniform", 128, every + ("agnn_epoch",)),
+                                   ("ogbn-products", "uniform", 128, every + ("gcn_epoch", "agnn_epoch")),
                                    ("ogbn-products", "sbm", 128, every),
                                    ("ogbn-products", "rmat", 128, every)):
             try:
@@ -531,10 +543,9 @@ def single_gpu(args):
                                                         "gcn_h16_epoch": sum(r["gcn_speedup_vs_rtx3090"] > 1 for r in good), "of": len(shapes)}
         cs = [r for r in good if r["shape"] == "citeseer"]
         if cs:   # BASELINE.json configs[1]: "Citeseer GCN hidden=16 TC-SpMM single-kernel" - the one published number for a named config
-            out["vs_baseline"] = cs[0]["spmm_speedup_vs_rtx3090"]
-            out["vs_baseline_note"] = ("BASELINE.md publishes no GTEPS and nothing at Reddit size; vs_baseline = the reference's single-kernel time on citeseer "
-                                       "(0.040 ms, RTX 3090, logs/profile.csv:2) / this run's time on the citeseer-size graph (%.4f ms): > 1 = faster than the reference"
-                                       % cs[0]["spmm_d16_ms"])
+            # (vs_baseline stays null: BASELINE.md publishes no GTEPS and nothing at Reddit size.  The one published number for a named
+            #  config is the reference's single-kernel time on citeseer, 0.040 ms on an RTX 3090, logs/profile.csv:2)
+            extra["citeseer_spmm_d16_speedup_vs_rtx3090"] = cs[0]["spmm_speedup_vs_rtx3090"]
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(rp_h.numpy(), col_h.numpy(), n, E, D, args.seed)
     out["extra"] = extra
@@ -698,7 +709,7 @@ def multi_gpu(args):
             "metric": "SpMM/SDDMM GTEPS + GCN/AGNN ms/epoch, Reddit h=64, 1xMI355X",
             "value": round(E_total * args.steps / t / 1e9, 3), "unit": "GTEPS (SpMM, edges/s/1e9)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 operands (TF32-equivalent rounding), f32 accumulate, f32 I/O", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 x f16 -> f32 (MFMA), f32 I/O", "data": "synthetic",
             "config": {"workload": "row-sharded %s-shape graph: %d nodes total, %d rows and ~%d nnz per GPU, SpMM D=%d, %s"
                                    % (args.shape, n_global, n0, E_local, D, "X all-gathered every step" if exchange else "X replicated (fits one GPU), no collective in the step"),
                        "parallelism": "row-window sharding x%d%s" % (world, ", RCCL all_gather_into_tensor of X" if exchange else "")},
@@ -738,6 +749,98 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+# ---- the line the driver parses.  r03's single object had grown to 20 KB and the driver's parser got nothing out of it
+#      (BENCH_r03.json "parsed": null): the LAST stdout line is now a bounded summary, everything else goes to bench_detail.json.
+LINE_LIMIT = 4000   # bytes; tests/test_bench_line.py holds the line to < 4096
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+CONFIG_KEYS = ("workload", "graph", "tc_blocks_16x8", "parallelism")
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel_ms_mean", "kernel_ms_min",
+             "kernel_ms_mean_all_launches", "mfma_busy", "l2_hit_rate")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model", "gcn_epoch_ms_cora_shape_h16", "gcn_epoch_ms_same_graph_h64")
+
+
+def _leg(d, key="kernel_ms"):
+    return d.get(key) if isinstance(d, dict) else None
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """The bounded last line: the contract's keys, `roofline`, `cpu_baseline` and a flat `summary` of scalars (most important
+    first; trailing ones are dropped until the line fits `limit`).  Strings are clipped; nothing nested below two levels."""
+    clip = lambda v, n=160: (v[:n] if isinstance(v, str) else v)
+    line = {k: clip(out[k]) for k in TOP_KEYS if k in out}
+    line["config"] = {k: clip(out.get("config", {}).get(k)) for k in CONFIG_KEYS if k in out.get("config", {})}
+    line["roofline"] = {k: clip(out.get("roofline", {}).get(k), 80) for k in ROOF_KEYS if k in out.get("roofline", {})}
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: clip(out["cpu_baseline"].get(k), 120) for k in CPU_KEYS if k in out["cpu_baseline"]}
+    ex = out.get("extra", {})
+    summary = []   # (name, value) in order of importance
+    D = None
+    for k in ex:
+        m = re.match(r"sddmm_d(\d+)$", k)
+        if m and "agnn_fused_fwd_d" + m.group(1) in ex:
+            D = m.group(1)
+    if D:
+        for name, key in (("sddmm_d%s_ms", "sddmm_d%s"), ("sddmm_d%s_frac", None), ("spmm_agnn_d%s_ms", "spmm_agnn_d%s"), ("agnn_fused_fwd_d%s_ms", "agnn_fused_fwd_d%s"),
+                          ("agnn_fused_bwd_d%s_ms", "agnn_fused_bwd_d%s")):
+            if key is None:
+                summary.append((name % D, _leg(ex.get("sddmm_d%s" % D), "hbm_frac")))
+            else:
+                summary.append((name % D, _leg(ex.get(key % D))))
+    for k in ("gcn_ms_per_epoch", "agnn_ms_per_epoch"):
+        summary.append((k, ex.get(k)))
+    for row in out.get("datasets", []):   # the graph calibrated to real Reddit's TC-block count, next to the uniform headline
+        if isinstance(row, dict) and row.get("workload", "").endswith("_sbm_reddit_d%s" % (D or "")) and isinstance(row.get("spmm"), dict):
+            summary += [("sbm_reddit_spmm_ms", row["spmm"].get("kernel_ms")), ("sbm_reddit_spmm_frac", row["spmm"].get("hbm_frac")),
+                        ("sbm_reddit_spmm_kernel", clip(row["spmm"].get("kernel"), 40)), ("sbm_reddit_tc_blocks_16x8", row.get("tc_blocks_16x8")),
+                        ("sbm_reddit_gcn_ms_per_epoch", row.get("gcn_ms_per_epoch")), ("sbm_reddit_agnn_ms_per_epoch", row.get("agnn_ms_per_epoch"))]
+        if isinstance(row, dict) and row.get("workload", "").endswith("_rmat_d%s" % (D or "")) and isinstance(row.get("spmm"), dict):
+            summary += [("rmat_spmm_ms", row["spmm"].get("kernel_ms"))]
+        if isinstance(row, dict) and row.get("workload") == "products_uniform_d128":
+            summary += [("products_d128_%s_ms" % op, _leg(row.get(op))) for op in ("spmm", "sddmm", "spmm_val")]
+            summary += [("products_d128_sddmm_frac", _leg(row.get("sddmm"), "hbm_frac")), ("products_agnn_h128_ms_per_epoch", row.get("agnn_ms_per_epoch")),
+                        ("products_gcn_h128_ms_per_epoch", row.get("gcn_ms_per_epoch"))]
+    for k in ("spmm_d16", "spmm_d128", "sddmm_d16", "sddmm_d128"):
+        summary.append((k + "_ms", _leg(ex.get(k))))
+    for k in ("gcn_h16_ms_per_epoch", "gcn_h128_ms_per_epoch", "agnn_h16_ms_per_epoch", "agnn_h128_ms_per_epoch"):
+        summary.append((k, ex.get(k)))
+    sk = [k for k in ex if k.endswith("_skewed_graph")]
+    if sk:
+        summary.append(("skewed_spmm_ms", _leg(ex[sk[0]])))
+    summary += [("value_all_launches", out.get("value_all_launches")), ("host_sgt_ms", ex.get("host_sgt_ms")), ("device_sgt_ms", ex.get("device_sgt_ms")),
+                ("device_sgt_equals_host_sgt", ex.get("device_sgt_equals_host_sgt")), ("plan_bytes", ex.get("plan_bytes")),
+                ("citeseer_spmm_d16_speedup_vs_rtx3090", ex.get("citeseer_spmm_d16_speedup_vs_rtx3090"))]
+    beat = ex.get("artifact_shapes_beating_rtx3090")
+    if isinstance(beat, dict):
+        summary.append(("artifact_shapes_beating_rtx3090", "%s/%s spmm_d16, %s/%s gcn_h16" % (beat.get("spmm_d16"), beat.get("of"), beat.get("gcn_h16_epoch"), beat.get("of"))))
+    for k in ("exchange_in_timed_step", "ms_per_step_without_exchange", "exchange_fraction_if_exchanged", "gcn_ms_per_epoch_sharded",
+              "ms_per_step_with_fp16_exchange", "ms_per_step_with_overlapped_exchange"):   # (the N > 1 line)
+        if k in ex:
+            summary.append((k, ex[k]))
+    summary = [(k, v) for k, v in summary if v is not None]
+    if out.get("detail"):
+        line["detail"] = out["detail"]
+    line["summary"] = dict(summary)
+    while len(json.dumps(line)) > limit and line["summary"]:
+        line["summary"].pop(next(reversed(line["summary"])))
+    return line
+
+
+def write_detail(out):
+    """Everything the run measured (per-dataset rows, the artifact-shape table, notes) as one JSON document: bench_detail.json
+    next to this file and, on a gpurun box, under gpurun_out/ so that it is merged back.  -> the path(s) written, for the line."""
+    written = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                json.dump(out, f, indent=1)
+            written.append(os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT))
+        except OSError:
+            pass
+    return written
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -748,6 +851,9 @@ def main():
     else:
         out = single_gpu(args)
     if out is not None:
+        written = write_detail(out)
+        if written:
+            out["detail"] = written[0]
         # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe or a file and would come
         # out AFTER this line at exit: drain it first so that the JSON line is the last thing on stdout
         try:
@@ -756,7 +862,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact_line(out)), flush=True)
 
 
 if __name__ == "__main__":

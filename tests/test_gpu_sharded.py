@@ -341,11 +341,38 @@ def test_bench_gpus_n_starts_its_own_ranks_and_prints_one_json_line_last():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines[-1]) < 4096, len(lines[-1])          # (the driver parses this line; r03's 20 KB object came back unparsed)
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms_mean"] > 0
-    ex = line["extra"]
+    s = line["summary"]
+    assert s["exchange_in_timed_step"] is True and s["gcn_ms_per_epoch_sharded"] is not None
+    with open(os.path.join(root, line["detail"])) as f:   # everything else: bench_detail.json
+        ex = json.load(f)["extra"]
     assert ex["exchange_in_timed_step"] is True
     assert ex["ms_per_step_with_exchange"] > 0 and ex["ms_per_step_with_fp16_exchange"] is not None
     assert ex["gcn_ms_per_epoch_sharded"] is not None
     assert ex["ms_per_step_with_overlapped_exchange"] is not None and 0.0 <= ex["exchange_fraction_if_overlapped"] < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_is_bounded_and_carries_roofline_and_cpu_baseline():
+    """The N = 1 form the driver runs (scaled down): last stdout line < 4 KB, parses, holds `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TCGNN_BENCH_FORCE_SHARDED"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scale", "0.05", "--steps", "5", "--warmup", "2", "--epochs", "3"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    line = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line, k
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+    assert line["summary"]["gcn_ms_per_epoch"] > 0 and line["summary"]["agnn_ms_per_epoch"] > 0
