@@ -39,8 +39,8 @@
  *     bits) of them for an SpMM, min(2 D, that number) for SDDMM and the fused AGNN pair - could leave the contract's
  *     1e-3 max(1, |ref|): max|X| >= 2^29 / k (binary SpMM), max|A| max|X| >= 2^28 / k (edge-valued), max|X|^2 >= 2^29 / k
  *     (SDDMM, fused AGNN).  A training epoch's activations (one stray 1e-5 among 1e4's) stay on the MFMA path.  Images the
- *     CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path: their
- *     header bytes 4 .. 255 must be zero.
+ *     CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path (the call
+ *     clears the reserved header words itself).
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
  *     TCGNN_kernel.cu:420).
@@ -243,7 +243,9 @@ int tcgnn_spmm_gemm(const tcgnn_plan* plan, const float* d_X, const float* d_W, 
  *   tcgnn_stage_absmax : atomicMax of the |X| bit patterns of n elements into *d_word (zero it first);
  *   tcgnn_stage_rows   : `rows` rows of X -> rows + 1 image rows at d_dst (the extra row is zero), scaled by *d_absmax_word
  *                        exactly as tcgnn_spmm would;
- *   tcgnn_spmm_staged  : Y = A_bin * X from such an image (gather walks; results identical to tcgnn_spmm on the same walk). */
+ *   tcgnn_spmm_staged  : Y = A_bin * X from such an image (gather walks; results identical to tcgnn_spmm on the same walk).
+ *                        Header words 1 .. 7 (bytes 4 .. 31) are RESERVED for the range guard and are cleared by the call on
+ *                        `stream` (a staged image is never "wide"); bytes 32 .. 255 are ignored.  The image is otherwise read-only. */
 int tcgnn_x16_pitch(int32_t D);
 int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream);
 int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, void* stream);

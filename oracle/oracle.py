@@ -46,6 +46,8 @@ def lib():
         _LIB.oracle_preprocess.argtypes = [i32p, i32p, c_i32, c_i32, c_i32, i32p, c_i64, i32p, i32p, i64p]
         _LIB.oracle_spmm.argtypes = [i32p] * 5 + [c_i32, c_i64, c_i32, c_i32, f32p, f32p, f32p, c_i32, c_i32, c_i32, c_i32]
         _LIB.oracle_sddmm.argtypes = [i32p] * 5 + [c_i32, c_i64, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32]
+        _LIB.oracle_spmm_windows.argtypes = [i32p] * 5 + [c_i32, c_i32, f32p, f32p, f32p, c_i32, i32p, c_i32]
+        _LIB.oracle_sddmm_windows.argtypes = [i32p] * 5 + [c_i32, c_i64, c_i32, f32p, f32p, c_i32, i32p, c_i32]
         _LIB.oracle_spmm_f64.argtypes = [i32p, i32p, c_i32, c_i32, f32p, f32p, f64p, f64p]
         _LIB.oracle_sddmm_f64.argtypes = [i32p, i32p, c_i32, c_i32, f32p, f64p, f64p]
         _LIB.oracle_csr_spmm.argtypes = [i32p, i32p, c_i32, c_i32, f32p, f32p, c_i32]
@@ -108,6 +110,40 @@ def sddmm(X, rowptr, col, bp, e2c, e2r, round_mode=ROUND_TF32, scale_exp_x=0, re
     lib().oracle_sddmm(pr, pc, pb, p2c, p2r, N, col.shape[0], bp.shape[0], D, px,
                        ef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), round_mode, scale_exp_x, int(ref_quirks))
     return ef
+
+
+def spmm_windows(X, rowptr, col, bp, e2c, e2r, windows, att=None, round_mode=ROUND_TF32):
+    """The oracle's thread-block body (oracle_spmm) for the listed row windows only -> (rows, Y_rows): the row numbers of those
+    windows and their result rows.  For graphs at BASELINE size, where the whole oracle product is minutes of CPU work."""
+    X, px = _f32(X)
+    rowptr, pr = _i32(rowptr); col, pc = _i32(col); bp, pb = _i32(bp); e2c, p2c = _i32(e2c); e2r, p2r = _i32(e2r)
+    windows, pw = _i32(windows)
+    N, D = rowptr.shape[0] - 1, X.shape[1]
+    rows = (windows[:, None].astype(np.int64) * 16 + np.arange(16)[None, :]).reshape(-1)
+    rows = rows[rows < N]
+    Y = np.zeros((N, D), dtype=np.float32)
+    pa = None
+    if att is not None:
+        att, pa = _f32(np.asarray(att).reshape(-1)[: col.shape[0]])
+    rc = lib().oracle_spmm_windows(pr, pc, pb, p2c, p2r, N, D, px, pa, Y.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), round_mode, pw, windows.shape[0])
+    if rc:
+        raise MemoryError("oracle_spmm_windows")
+    return rows, Y[rows]
+
+
+def sddmm_windows(X, rowptr, col, bp, e2c, e2r, windows, round_mode=ROUND_TF32):
+    """oracle_sddmm's warp body for the listed row windows only -> (edges, ef_edges): the CSR positions of those windows' edges
+    and their scores."""
+    X, px = _f32(X)
+    rowptr, pr = _i32(rowptr); col, pc = _i32(col); bp, pb = _i32(bp); e2c, p2c = _i32(e2c); e2r, p2r = _i32(e2r)
+    windows, pw = _i32(windows)
+    N, D = rowptr.shape[0] - 1, X.shape[1]
+    ef = np.zeros(col.shape[0], dtype=np.float32)
+    lib().oracle_sddmm_windows(pr, pc, pb, p2c, p2r, N, col.shape[0], D, px, ef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), round_mode, pw, windows.shape[0])
+    lo = rowptr[np.minimum(windows.astype(np.int64) * 16, N)].astype(np.int64)
+    hi = rowptr[np.minimum(windows.astype(np.int64) * 16 + 16, N)].astype(np.int64)
+    edges = np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in zip(lo, hi)]) if len(windows) else np.zeros(0, np.int64)
+    return edges, ef[edges]
 
 
 def spmm_f64(X, rowptr, col, att=None):

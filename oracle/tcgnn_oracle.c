@@ -164,6 +164,64 @@ int oracle_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32
  * accumulation block after block.  Rows >= N of the last window are never stored (the reference
  * writes them out of bounds, :453).  Y is fully overwritten (reference: zeros_like then store).
  */
+/* one row window of oracle_spmm (the body of the reference's thread block, TCGNN_kernel.cu:336-454 / :459-578); `Ncols` = rows of X
+ * (== N for the square graphs the reference handles; the sentinel test of :423 is against it) */
+static int spmm_window(int32_t bid, const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
+                       const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int64_t Ncols, int32_t D, int32_t dlimit,
+                       const float* X, const float* edgeAttention, float* Y, int32_t round_mode, float sx, float isx, float sa, float isa) {
+    int64_t n0 = (int64_t)bid * BLK_H;
+    if (n0 >= N) return 0;
+    int64_t n1 = n0 + BLK_H; if (n1 > N) n1 = N;
+    int64_t e0 = nodePointer[n0], e1 = nodePointer[n1];
+    int32_t ntc = blockPartition[bid];
+    float* acc = (float*)calloc((size_t)BLK_H * (size_t)D, sizeof(float));
+    /* bucket the window's edges by TC block (the reference rescans all of them per block,
+     * :400-408; bucketing visits the same edges per block in the same order) */
+    int64_t ne = e1 - e0;
+    int32_t* cnt = (int32_t*)calloc((size_t)ntc + 1, sizeof(int32_t));
+    int64_t* order = (int64_t*)malloc((size_t)(ne > 0 ? ne : 1) * sizeof(int64_t));
+    if (!acc || !cnt || !order) { free(acc); free(cnt); free(order); return -1; }
+    for (int64_t e = e0; e < e1; e++) { int32_t b = edgeToColumn[e] / BLK_W; if (b < ntc) cnt[b + 1]++; }
+    for (int32_t b = 0; b < ntc; b++) cnt[b + 1] += cnt[b];
+    int32_t* fill = (int32_t*)calloc((size_t)ntc + 1, sizeof(int32_t));
+    for (int64_t e = e0; e < e1; e++) { int32_t b = edgeToColumn[e] / BLK_W; if (b < ntc) order[cnt[b] + fill[b]++] = e; }
+    free(fill);
+    for (int32_t i = 0; i < ntc; i++) {
+        float sparse_A[BLK_H * BLK_W];
+        int64_t AToX[BLK_W];
+        memset(sparse_A, 0, sizeof(sparse_A));
+        for (int k = 0; k < BLK_W; k++) AToX[k] = Ncols + 1;                      /* :379 sentinel */
+        for (int32_t p = cnt[i]; p < cnt[i + 1]; p++) {
+            int64_t e = order[p];
+            int32_t col = edgeToColumn[e];
+            int32_t row_local = edgeToRow[e] % BLK_H, col_local = col % BLK_W;
+            sparse_A[row_local * BLK_W + col_local] = edgeAttention ? edgeAttention[e] : 1.0f;
+            AToX[col_local] = edgeList[e];
+        }
+        for (int k = 0; k < BLK_W; k++) {
+            const int64_t src_row = AToX[k];
+            float a_col[BLK_H];
+            int any = 0;
+            for (int r = 0; r < BLK_H; r++) {
+                float a = sparse_A[r * BLK_W + k];
+                a_col[r] = edgeAttention ? round_operand(a, round_mode, sa, isa) : a;
+                any |= (a_col[r] != 0.0f);
+            }
+            if (!any || src_row >= Ncols) continue; /* zero column / zero-filled X row (:423-424) */
+            const float* xr = X + (size_t)src_row * (size_t)D;
+            for (int32_t d = 0; d < dlimit; d++) {
+                float xv = round_operand(xr[d], round_mode, sx, isx);
+                for (int r = 0; r < BLK_H; r++)
+                    if (a_col[r] != 0.0f) acc[r * D + d] += a_col[r] * xv;
+            }
+        }
+    }
+    for (int64_t r = n0; r < n1; r++)
+        memcpy(Y + (size_t)r * (size_t)D, acc + (size_t)(r - n0) * (size_t)D, (size_t)dlimit * sizeof(float));
+    free(acc); free(cnt); free(order);
+    return 0;
+}
+
 int oracle_spmm(const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
                 const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int64_t E,
                 int32_t nw, int32_t D, const float* X, const float* edgeAttention, float* Y,
@@ -179,58 +237,22 @@ int oracle_spmm(const int32_t* nodePointer, const int32_t* edgeList, const int32
     memset(Y, 0, (size_t)N * (size_t)D * sizeof(float));
     int rc = 0;
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int32_t bid = 0; bid < nw; bid++) {
-        int64_t n0 = (int64_t)bid * BLK_H;
-        if (n0 >= N) continue;
-        int64_t n1 = n0 + BLK_H; if (n1 > N) n1 = N;
-        int64_t e0 = nodePointer[n0], e1 = nodePointer[n1];
-        int32_t ntc = blockPartition[bid];
-        float* acc = (float*)calloc((size_t)BLK_H * (size_t)D, sizeof(float));
-        /* bucket the window's edges by TC block (the reference rescans all of them per block,
-         * :400-408; bucketing visits the same edges per block in the same order) */
-        int64_t ne = e1 - e0;
-        int32_t* cnt = (int32_t*)calloc((size_t)ntc + 1, sizeof(int32_t));
-        int64_t* order = (int64_t*)malloc((size_t)(ne > 0 ? ne : 1) * sizeof(int64_t));
-        if (!acc || !cnt || !order) { rc = -1; free(acc); free(cnt); free(order); continue; }
-        for (int64_t e = e0; e < e1; e++) { int32_t b = edgeToColumn[e] / BLK_W; if (b < ntc) cnt[b + 1]++; }
-        for (int32_t b = 0; b < ntc; b++) cnt[b + 1] += cnt[b];
-        int32_t* fill = (int32_t*)calloc((size_t)ntc + 1, sizeof(int32_t));
-        for (int64_t e = e0; e < e1; e++) { int32_t b = edgeToColumn[e] / BLK_W; if (b < ntc) order[cnt[b] + fill[b]++] = e; }
-        free(fill);
-        for (int32_t i = 0; i < ntc; i++) {
-            float sparse_A[BLK_H * BLK_W];
-            int64_t AToX[BLK_W];
-            memset(sparse_A, 0, sizeof(sparse_A));
-            for (int k = 0; k < BLK_W; k++) AToX[k] = (int64_t)N + 1;            /* :379 sentinel */
-            for (int32_t p = cnt[i]; p < cnt[i + 1]; p++) {
-                int64_t e = order[p];
-                int32_t col = edgeToColumn[e];
-                int32_t row_local = edgeToRow[e] % BLK_H, col_local = col % BLK_W;
-                sparse_A[row_local * BLK_W + col_local] = edgeAttention ? edgeAttention[e] : 1.0f;
-                AToX[col_local] = edgeList[e];
-            }
-            for (int k = 0; k < BLK_W; k++) {
-                const int64_t src_row = AToX[k];
-                float a_col[BLK_H];
-                int any = 0;
-                for (int r = 0; r < BLK_H; r++) {
-                    float a = sparse_A[r * BLK_W + k];
-                    a_col[r] = edgeAttention ? round_operand(a, round_mode, sa, isa) : a;
-                    any |= (a_col[r] != 0.0f);
-                }
-                if (!any || src_row >= N) continue; /* zero column / zero-filled X row (:423-424) */
-                const float* xr = X + (size_t)src_row * (size_t)D;
-                for (int32_t d = 0; d < dlimit; d++) {
-                    float xv = round_operand(xr[d], round_mode, sx, isx);
-                    for (int r = 0; r < BLK_H; r++)
-                        if (a_col[r] != 0.0f) acc[r * D + d] += a_col[r] * xv;
-                }
-            }
-        }
-        for (int64_t r = n0; r < n1; r++)
-            memcpy(Y + (size_t)r * (size_t)D, acc + (size_t)(r - n0) * (size_t)D, (size_t)dlimit * sizeof(float));
-        free(acc); free(cnt); free(order);
-    }
+    for (int32_t bid = 0; bid < nw; bid++)
+        if (spmm_window(bid, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, N, (int64_t)N, D, dlimit, X, edgeAttention, Y,
+                        round_mode, sx, isx, sa, isa)) rc = -1;
+    return rc;
+}
+
+/* The same thread-block body for a LIST of row windows of a big graph (tests at BASELINE size: the whole product takes the oracle
+ * minutes, `nsel` sampled windows a second).  Only the rows of the listed windows of Y are written. */
+int oracle_spmm_windows(const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
+                        const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int32_t D, const float* X,
+                        const float* edgeAttention, float* Y, int32_t round_mode, const int32_t* windows, int32_t nsel) {
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t k = 0; k < nsel; k++)
+        if (spmm_window(windows[k], nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, N, (int64_t)N, D, D, X, edgeAttention, Y,
+                        round_mode, 1.0f, 1.0f, 1.0f, 1.0f)) rc = -1;
     return rc;
 }
 
@@ -241,63 +263,85 @@ int oracle_spmm(const int32_t* nodePointer, const int32_t* edgeList, const int32
  * output tiles (num_TC_blocks = ceil(bp*8/16), :611), k in steps of 8 (:604,667), fp32
  * accumulate.  ef is zero-initialised (:298).
  */
+/* one row window of oracle_sddmm (the reference's warp, TCGNN_kernel.cu:584-727) */
+static void sddmm_window(int32_t bid, const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
+                         const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int64_t E, int32_t D, const float* X, float* ef,
+                         int32_t round_mode, float sx, float isx, int32_t ref_quirks) {
+    const int64_t bound = (int64_t)N * (int64_t)D;
+    const int32_t ksteps = (D + BLK_W - 1) / BLK_W;
+    int64_t n0 = (int64_t)bid * BLK_H;
+    if (n0 >= N) return;
+    int64_t n1 = n0 + BLK_H; if (n1 > N) n1 = N;
+    int64_t e0 = nodePointer[n0], e1 = nodePointer[n1];
+    int32_t ntc = (blockPartition[bid] * BLK_W + BLK_H - 1) / BLK_H;
+    for (int32_t i = 0; i < ntc; i++) {
+        int64_t tileE[BLK_H * BLK_H];
+        int64_t AToX[BLK_H];
+        for (int t = 0; t < BLK_H * BLK_H; t++) tileE[t] = E + 1;   /* :641 */
+        for (int t = 0; t < BLK_H; t++) AToX[t] = (int64_t)N + 1;
+        int any = 0;
+        for (int64_t e = e0; e < e1; e++) {                          /* :656-663 */
+            int32_t col = edgeToColumn[e];
+            if ((int64_t)i * BLK_H <= col && col < ((int64_t)i + 1) * BLK_H) {
+                int32_t row = edgeToRow[e] % BLK_H;
+                int64_t id = e;
+                if (ref_quirks) id = (int64_t)(float)e;              /* float round-trip */
+                tileE[row * BLK_H + col % BLK_H] = id;
+                AToX[col % BLK_H] = edgeList[e];
+                any = 1;
+            }
+        }
+        if (!any) continue;
+        float acc[BLK_H * BLK_H];
+        memset(acc, 0, sizeof(acc));
+        for (int32_t kk = 0; kk < ksteps; kk++) {
+            float dX[BLK_H * BLK_W], dY[BLK_H * BLK_W];
+            for (int r = 0; r < BLK_H; r++)
+                for (int d = 0; d < BLK_W; d++) {
+                    int32_t dim = kk * BLK_W + d;
+                    int64_t sX = (n0 + r) * (int64_t)D + dim;          /* :675 */
+                    int64_t sY = AToX[r] * (int64_t)D + dim;           /* :689 */
+                    int okX = sX < bound, okY = sY < bound;
+                    if (!ref_quirks) { okX = okX && dim < D && (n0 + r) < N; okY = okY && dim < D && AToX[r] < N; }
+                    dX[r * BLK_W + d] = okX ? round_operand(X[sX], round_mode, sx, isx) : 0.0f;
+                    dY[r * BLK_W + d] = okY ? round_operand(X[sY], round_mode, sx, isx) : 0.0f;
+                }
+            for (int r = 0; r < BLK_H; r++)
+                for (int c = 0; c < BLK_H; c++) {
+                    float s = acc[r * BLK_H + c];
+                    for (int d = 0; d < BLK_W; d++) s += dX[r * BLK_W + d] * dY[c * BLK_W + d];
+                    acc[r * BLK_H + c] = s;
+                }
+        }
+        for (int t = 0; t < BLK_H * BLK_H; t++)                      /* :719-726 */
+            if (tileE[t] < E) ef[tileE[t]] = acc[t];
+    }
+}
+
 int oracle_sddmm(const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
                  const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int64_t E,
                  int32_t nw, int32_t D, const float* X, float* ef, int32_t round_mode,
                  int32_t scale_exp_x, int32_t ref_quirks) {
     const float sx = ldexpf(1.0f, scale_exp_x), isx = ldexpf(1.0f, -scale_exp_x);
-    const int64_t bound = (int64_t)N * (int64_t)D;
-    const int32_t ksteps = (D + BLK_W - 1) / BLK_W;
     memset(ef, 0, (size_t)E * sizeof(float));
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int32_t bid = 0; bid < nw; bid++) {
-        int64_t n0 = (int64_t)bid * BLK_H;
+    for (int32_t bid = 0; bid < nw; bid++)
+        sddmm_window(bid, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, N, E, D, X, ef, round_mode, sx, isx, ref_quirks);
+    return 0;
+}
+
+/* the same warp body for a list of row windows (see oracle_spmm_windows); only the edges of the listed windows are written
+ * (zeroed first, as :298 zero-initialises the whole output) */
+int oracle_sddmm_windows(const int32_t* nodePointer, const int32_t* edgeList, const int32_t* blockPartition,
+                         const int32_t* edgeToColumn, const int32_t* edgeToRow, int32_t N, int64_t E, int32_t D, const float* X,
+                         float* ef, int32_t round_mode, const int32_t* windows, int32_t nsel) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t k = 0; k < nsel; k++) {
+        int64_t n0 = (int64_t)windows[k] * BLK_H, n1 = n0 + BLK_H;
         if (n0 >= N) continue;
-        int64_t n1 = n0 + BLK_H; if (n1 > N) n1 = N;
-        int64_t e0 = nodePointer[n0], e1 = nodePointer[n1];
-        int32_t ntc = (blockPartition[bid] * BLK_W + BLK_H - 1) / BLK_H;
-        for (int32_t i = 0; i < ntc; i++) {
-            int64_t tileE[BLK_H * BLK_H];
-            int64_t AToX[BLK_H];
-            for (int t = 0; t < BLK_H * BLK_H; t++) tileE[t] = E + 1;   /* :641 */
-            for (int t = 0; t < BLK_H; t++) AToX[t] = (int64_t)N + 1;
-            int any = 0;
-            for (int64_t e = e0; e < e1; e++) {                          /* :656-663 */
-                int32_t col = edgeToColumn[e];
-                if ((int64_t)i * BLK_H <= col && col < ((int64_t)i + 1) * BLK_H) {
-                    int32_t row = edgeToRow[e] % BLK_H;
-                    int64_t id = e;
-                    if (ref_quirks) id = (int64_t)(float)e;              /* float round-trip */
-                    tileE[row * BLK_H + col % BLK_H] = id;
-                    AToX[col % BLK_H] = edgeList[e];
-                    any = 1;
-                }
-            }
-            if (!any) continue;
-            float acc[BLK_H * BLK_H];
-            memset(acc, 0, sizeof(acc));
-            for (int32_t kk = 0; kk < ksteps; kk++) {
-                float dX[BLK_H * BLK_W], dY[BLK_H * BLK_W];
-                for (int r = 0; r < BLK_H; r++)
-                    for (int d = 0; d < BLK_W; d++) {
-                        int32_t dim = kk * BLK_W + d;
-                        int64_t sX = (n0 + r) * (int64_t)D + dim;          /* :675 */
-                        int64_t sY = AToX[r] * (int64_t)D + dim;           /* :689 */
-                        int okX = sX < bound, okY = sY < bound;
-                        if (!ref_quirks) { okX = okX && dim < D && (n0 + r) < N; okY = okY && dim < D && AToX[r] < N; }
-                        dX[r * BLK_W + d] = okX ? round_operand(X[sX], round_mode, sx, isx) : 0.0f;
-                        dY[r * BLK_W + d] = okY ? round_operand(X[sY], round_mode, sx, isx) : 0.0f;
-                    }
-                for (int r = 0; r < BLK_H; r++)
-                    for (int c = 0; c < BLK_H; c++) {
-                        float s = acc[r * BLK_H + c];
-                        for (int d = 0; d < BLK_W; d++) s += dX[r * BLK_W + d] * dY[c * BLK_W + d];
-                        acc[r * BLK_H + c] = s;
-                    }
-            }
-            for (int t = 0; t < BLK_H * BLK_H; t++)                      /* :719-726 */
-                if (tileE[t] < E) ef[tileE[t]] = acc[t];
-        }
+        if (n1 > N) n1 = N;
+        for (int64_t e = nodePointer[n0]; e < nodePointer[n1]; e++) ef[e] = 0.0f;
+        sddmm_window(windows[k], nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, N, E, D, X, ef, round_mode, 1.0f, 1.0f, 0);
     }
     return 0;
 }

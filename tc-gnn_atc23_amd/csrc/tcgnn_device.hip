@@ -200,7 +200,9 @@ __device__ __forceinline__ void count_tiny(uint32_t* cnt, uint32_t mine) {   // 
     for (int b = 0; b < 4; ++b) total += (uint32_t)__popcll(__ballot((mine >> b) & 1u)) << b;
     if (total && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(cnt, total);
 }
-__device__ __forceinline__ uint32_t is_tiny(float scaled) { const float a = fabsf(scaled); return (a > 0.0f && a < 6.103515625e-5f) ? 1u : 0u; }
+// (decided on the SOURCE element and its scaled fp32 value, not on the converted half: an element more than 2^39 below the maximum
+//  converts to exactly 0 and must still count - ADVICE r03: one 1e12 among O(1) data had n_tiny = 0 and stayed on the MFMA path)
+__device__ __forceinline__ uint32_t is_tiny(float x, float s) { return (x != 0.0f && fabsf(x * s) < 6.103515625e-5f) ? 1u : 0u; }
 
 // Round to a 10-bit mantissa, nearest with ties AWAY from zero: bit-for-bit what the reference's
 // wmma::__float_to_tf32 (cvt.rna.tf32.f32, TCGNN_kernel.cu:441-444) does.  The result has at most
@@ -430,26 +432,28 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
     const int d0 = (int)(q - row * cpr) * 8;
     const float s = pow2f(scale_exp_from_bits(hdr[0]));
     half8 o;
+    uint32_t nt = 0;   // elements that lose bits in the image (range guard): nonzero, below fp16's normal range once scaled
     if (row < N && VEC && d0 + 8 <= D) {
         const float4* src = reinterpret_cast<const float4*>(X + row * ldx + d0);
         const float4 a = src[0], b = src[1];
-        o[0] = to_half_rna(a.x * s); o[1] = to_half_rna(a.y * s); o[2] = to_half_rna(a.z * s); o[3] = to_half_rna(a.w * s);
-        o[4] = to_half_rna(b.x * s); o[5] = to_half_rna(b.y * s); o[6] = to_half_rna(b.z * s); o[7] = to_half_rna(b.w * s);
-        if (G) {
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (!(G[row * ldx + d0 + j] > 0.0f)) o[j] = (_Float16)0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const bool on = !G || G[row * ldx + d0 + j] > 0.0f;
+            o[j] = on ? to_half_rna(v[j] * s) : (_Float16)0.0f;
+            nt += on ? is_tiny(v[j], s) : 0u;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int d = d0 + j;
-            o[j] = (row < N && d < D && (!G || G[row * ldx + d] > 0.0f)) ? to_half_rna(X[row * ldx + d] * s) : (_Float16)0.0f;
+            const bool on = row < N && d < D && (!G || G[row * ldx + d] > 0.0f);
+            const float v = on ? X[row * ldx + d] : 0.0f;
+            o[j] = to_half_rna(v * s);
+            nt += is_tiny(v, s);
         }
     }
     *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
-    uint32_t nt = 0;   // elements that lose bits in the image (range guard): nonzero, below fp16's normal range
-#pragma unroll
-    for (int j = 0; j < 8; ++j) nt += is_tiny((float)o[j]);
     count_tiny(tiny, nt);
 }
 
@@ -3774,6 +3778,11 @@ int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* 
 
 int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream) {
     if (!d_image || (reinterpret_cast<uintptr_t>(d_image) & 255)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_staged: the image must be 256-byte aligned");
+    // Every MFMA kernel opens with the range guard's test on header words 2, 4, 6, 7; a caller-staged image carries no range words
+    // (never "wide": there is no fp32 X to fall back to).  The reserved words 1 .. 7 are cleared here, on the caller's stream, so a
+    // header a caller left uninitialised beyond word 0 cannot make the kernels return early with Y unwritten.
+    if (hipMemsetAsync(static_cast<char*>(const_cast<void*>(d_image)) + 4, 0, 28, static_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(TCGNN_ERR_HIP, "tcgnn_spmm_staged: clearing the reserved header words failed");
     return run_spmm(plan, nullptr, nullptr, d_Y, D, nullptr, 0, stream, 0, nullptr, d_image);
 }
 

@@ -411,6 +411,10 @@ class GCNConv(torch.nn.Module):
         return torch.relu(y) if fuse_relu else y
 
 
+# GINConv's one-launch inference form (tcgnn_spmm_gemm); see GINConv.forward
+GIN_FUSED_INFERENCE = os.environ.get("TCGNN_GIN_FUSED_INFERENCE", "1") != "0"
+
+
 class GINConv(torch.nn.Module):
     def __init__(self, input_dim, output_dim):
         super().__init__()
@@ -421,8 +425,12 @@ class GINConv(torch.nn.Module):
         # (A X) W of tcgnn_spmm_gemm - decided HERE, from the grad mode: inside a Function `needs_input_grad` only mirrors
         # `requires_grad`, so under model.eval() + torch.no_grad() with ordinary Parameters it never fired (r2 ADVICE).
         # forward_gemm is inference-only: it has no backward.
+        # The shortcut sums in another order than forward + torch.mm (fp32 matrix pipe behind the aggregation; on 64-wide inputs two
+        # passes added atomically): equal within accumulation noise, not bit for bit - `GIN_FUSED_INFERENCE = False` (or
+        # TCGNN_GIN_FUSED_INFERENCE=0) keeps eval on the training path's arithmetic (ADVICE r03;
+        # tests/test_gpu_parity.py::test_gin_layer_eval_and_train_forward_agree).
         b = backend()
-        if ((not torch.is_grad_enabled() or not (X.requires_grad or self.weights.requires_grad)) and X.is_cuda
+        if (GIN_FUSED_INFERENCE and (not torch.is_grad_enabled() or not (X.requires_grad or self.weights.requires_grad)) and X.is_cuda
                 and hasattr(b, "forward_gemm") and max(self.weights.shape) <= getattr(b, "GEMM_FUSED_MAX_DIM", 128)):
             return b.forward_gemm(X, self.weights.detach(), row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)[0]
         return TCGNNFunction_GIN.apply(X, self.weights, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow)

@@ -301,7 +301,8 @@ class RowShard:
         """Y_local = A_local @ all_gather(X) with the gather on a side stream under the own-block product (see above)."""
         own, rest = self._split_ops()
         D, H = x_local.shape[1], self.layout.H
-        key = (D, x_local.dtype)
+        # (its OWN buffer pair: `gather` hands its buffers to callers, who may still read them while the side stream writes here)
+        key = ("overlapped", D, x_local.dtype)
         buf = self._gbuf.get(key)
         if buf is None:
             buf = (torch.zeros(H, D, dtype=x_local.dtype, device=x_local.device),
@@ -327,7 +328,10 @@ class RowShard:
                 recv[:H].copy_(send)
         y = own.spmm(send)                           # ... while the blocks travel
         main.wait_stream(side)
-        recv.record_stream(main)
+        # both buffers were allocated on the main stream and are used on the side stream: that is the stream the allocator must
+        # be told about (harmless so far only because _gbuf keeps them alive)
+        send.record_stream(side)
+        recv.record_stream(side)
         return y.add_(rest.spmm(recv))
 
     def place_replicated(self, x_global):

@@ -1047,8 +1047,11 @@ def _wide_range_body(dev, T):
     rng = np.random.default_rng(11)
     T.set_range_guard(2)                                      # every operator (the default level guards the SpMM operators only)
     att = rng.standard_normal(len(col)).astype(np.float32)
-    for name, outlier, wide in (("outlier 3e7 over 1e-3 data", 3e7, True), ("1e-14 specks in O(1) data", None, False)):
-        X = (rng.standard_normal((n, D)) * 1e-3).astype(np.float32)
+    # (third case, ADVICE r03: an outlier 2^40 above the rest converts everything else to EXACTLY zero - nothing subnormal is left in
+    #  the image to count, so the count must come from the source values; before that fix n_tiny was 0 and the call stayed on MFMA)
+    for name, outlier, wide in (("outlier 3e7 over 1e-3 data", 3e7, True), ("1e-14 specks in O(1) data", None, False),
+                                ("outlier 1e12 over O(1) data: the rest flushes to zero", 1e12, True)):
+        X = (rng.standard_normal((n, D)) * (1e-3 if outlier is None or outlier < 1e10 else 1.0)).astype(np.float32)
         if outlier is not None:
             X[1234] = outlier * (1.0 + rng.random(D).astype(np.float32))
         else:
@@ -1076,7 +1079,7 @@ def _wide_range_body(dev, T):
         for got, want in ((Y, ref), (Yv, refv), (ef, refe)):
             assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= TOL
         if wide:   # the fp16 image alone would miss by orders of magnitude: the test is sensitive to the fallback
-            small_rows = np.abs(ref).max(axis=1) < 1.0
+            small_rows = np.abs(ref).max(axis=1) < (1.0 if outlier < 1e10 else 1e4)   # rows without an edge to the outlier row
             assert small_rows.sum() > n // 2 and err["spmm"][small_rows].max() <= 4 * TIGHT
         # the fused AGNN pair, forward and backward, against the separate operators' definitions
         w = np.float32(0.75)
@@ -1254,6 +1257,109 @@ def test_full_size_reddit_shape_properties(dev, T):
     lhs = ef.double().sum().item()
     rhs = (X1.double() * Y1.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * ef.double().abs().sum().item()
+    del X1, X2, Y1, Y2, Y12, Yv, ef, order_f, order_b, key_fwd, key_bwd
+    # ... and the oracle itself on a sample of row windows, every walk (the headline kernel among them)
+    kernels = _sampled_oracle_checks(dev, T, n, E, meta, 64, lds_ordinary=True)
+    if os.environ.get("TCGNN_LDS_AUTO", "1") != "0":
+        assert kernels["automatic spmm"].startswith("spmm_lds_flat_kernel"), kernels
+    T.clear_plan_cache()
+
+
+def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary=False):
+    """VERDICT r03 "oracle evidence at BASELINE size": the full-size tests above assert size-independent properties; here the SAME
+    launches are compared with the ORACLE itself on a sample - `nwin` random row windows (16 rows each: 4 096 rows, ~1-2 M edges
+    on the Reddit shape) evaluated by the oracle's own thread-block / warp bodies (oracle_spmm_windows / oracle_sddmm_windows =
+    TCGNN_kernel.cu:336-454, :459-578, :584-727 restated) on the full-size inputs, next to fp64 gathers of the definition on the
+    device - with the bounds of assert_parity (1e-3 max(1, |ref|); accumulation noise against the TF32-mode oracle; 2^-9 of the
+    sum of |terms| against fp64), for the automatic kernel AND every forced walk, for forward, forward_AGNN, forward_ef and the
+    fused AGNN pair."""
+    import tcgnn_capi as c
+    rp, col, bp, e2c, e2r = meta
+    host = tuple(t.cpu().numpy() for t in meta)
+    rng = np.random.default_rng(seed + D)
+    nw = (n + 15) // 16
+    windows = np.sort(rng.choice(nw, size=min(nwin, nw), replace=False)).astype(np.int32)
+    g = torch.Generator(device=dev).manual_seed(1000 + D + seed)
+    X = torch.randn(n, D, device=dev, generator=g)
+    att = torch.randn(E, device=dev, generator=g)
+    Xh, atth = X.cpu().numpy(), att.cpu().numpy()
+    rows, Yref = O.spmm_windows(Xh, *host, windows)
+    _, Yvref = O.spmm_windows(Xh, *host, windows, att=atth)
+    edges, efref = O.sddmm_windows(Xh, *host, windows)
+    # fp64 evaluation of the definitions for the sampled rows / edges, on the device
+    trows = torch.from_numpy(rows).to(dev)
+    lens = (rp[trows + 1] - rp[trows]).long()
+    seg = torch.repeat_interleave(torch.arange(len(rows), device=dev), lens)
+    first = torch.cumsum(lens, 0) - lens
+    eidx = rp[trows].long()[seg] + (torch.arange(int(lens.sum()), device=dev) - first[seg])
+    assert torch.equal(eidx, torch.from_numpy(edges).to(dev))           # (the oracle's edge list of the windows = the CSR's)
+    xc = X[col[eidx].long()].double()
+    Y64 = torch.zeros(len(rows), D, dtype=torch.float64, device=dev).index_add_(0, seg, xc)
+    A64 = torch.zeros_like(Y64).index_add_(0, seg, xc.abs())
+    av = att[eidx].double()[:, None]
+    Yv64 = torch.zeros_like(Y64).index_add_(0, seg, xc * av)
+    Av64 = torch.zeros_like(Y64).index_add_(0, seg, xc.abs() * av.abs())
+    xr = X[trows[seg]].double()
+    ef64 = (xr * xc).sum(1); aef64 = (xr * xc).abs().sum(1)
+    del xr, av
+    Y64, A64, Yv64, Av64, ef64, aef64 = (t.cpu().numpy() for t in (Y64, A64, Yv64, Av64, ef64, aef64))
+    tedges = eidx
+    w = torch.tensor([0.37], device=dev)
+    dY = torch.randn(n, D, device=dev, generator=g)
+    dYh = dY.cpu().numpy()
+    kernels = {}
+
+    def one_walk(tag, spmm_only=False):
+        got = T.forward(X, *meta)[0][trows].cpu().numpy()
+        kernels["%s spmm" % tag] = T.last_kernel(*meta)
+        assert_parity(got, Yref, Y64, A64, "full-size spmm D=%d, %s (%s)" % (D, tag, T.last_kernel(*meta)))
+        if spmm_only:
+            return
+        got = T.forward_AGNN(X, rp, col, att.view(1, -1), bp, e2c, e2r)[0][trows].cpu().numpy()
+        kernels["%s spmm_val" % tag] = T.last_kernel(*meta)
+        assert_parity(got, Yvref, Yv64, Av64, "full-size forward_AGNN D=%d, %s (%s)" % (D, tag, T.last_kernel(*meta)))
+        got = T.forward_ef(X, *meta)[0][tedges].cpu().numpy()
+        kernels["%s sddmm" % tag] = T.last_kernel(*meta)
+        assert_parity(got, efref, ef64, aef64, "full-size forward_ef D=%d, %s (%s)" % (D, tag, T.last_kernel(*meta)))
+        # the fused pair: scores against the oracle's SDDMM; the aggregation against the oracle's edge-valued SpMM fed with the edge
+        # weights the kernel itself produced (a score one accumulation-noise step away can round to the neighbouring 10-bit weight)
+        Yf, ef_f, efm = T.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r)
+        kernels["%s fused fwd" % tag] = T.last_kernel(*meta)
+        assert_parity(ef_f[tedges].cpu().numpy(), efref, ef64, aef64, "full-size fused ef D=%d, %s" % (D, tag))
+        att_k = (w * ef_f)
+        att_kh = att_k.cpu().numpy()
+        _, Yfref = O.spmm_windows(Xh, *host, windows, att=att_kh)
+        akk = att_k[eidx].double()[:, None]
+        xcc = X[col[eidx].long()].double()
+        Yf64 = torch.zeros(len(rows), D, dtype=torch.float64, device=dev).index_add_(0, seg, xcc * akk).cpu().numpy()
+        Af64 = torch.zeros(len(rows), D, dtype=torch.float64, device=dev).index_add_(0, seg, xcc.abs() * akk.abs()).cpu().numpy()
+        # (|att| ~ 0.37 sqrt(D) |x|^2: the 1e-3 bar is stated for O(1) operands - here the tight, scale-relative bounds decide)
+        assert_parity(Yf[trows].cpu().numpy(), Yfref, Yf64, Af64, "full-size fused Y D=%d, %s" % (D, tag), unit_scale=False)
+        G, _ = T.agnn_fused_backward(dY, rp, col, w, ef_f, efm, bp, e2c, e2r)
+        kernels["%s fused bwd" % tag] = T.last_kernel(*meta)
+        _, Gref = O.spmm_windows(dYh, *host, windows, att=att_kh)
+        dc = dY[col[eidx].long()].double()
+        G64 = torch.zeros(len(rows), D, dtype=torch.float64, device=dev).index_add_(0, seg, dc * akk).cpu().numpy()
+        Ag64 = torch.zeros(len(rows), D, dtype=torch.float64, device=dev).index_add_(0, seg, dc.abs() * akk.abs()).cpu().numpy()
+        assert_parity(G[trows].cpu().numpy(), Gref, G64, Ag64, "full-size fused G D=%d, %s" % (D, tag), unit_scale=False)
+
+    try:
+        for mode, tag in ((0, "automatic"), (1, "per-window walk"), (2, "range-blocked / range-major walk")):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            one_walk(tag)
+        if lds_ordinary:   # the ordinary cell stream of the LDS-resident kernel (what graphs with communities or hubs take)
+            os.environ["TCGNN_LDS_FLAT"] = "0"
+            T.clear_plan_cache()
+            try:
+                c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+                one_walk("LDS-resident, ordinary stream", spmm_only=True)
+                assert kernels["LDS-resident, ordinary stream spmm"].startswith("spmm_lds_kernel")
+            finally:
+                os.environ.pop("TCGNN_LDS_FLAT", None)
+                T.clear_plan_cache()
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    return kernels
 
 
 GEMM_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n1000", "empty_middle_window_n48", "powerlaw_n1000", "citeseer_shape", "dense_n3000_deg150", "no_edges_n20")]
@@ -1271,14 +1377,21 @@ def test_dense_update_fused_behind_the_aggregation(dev, T, case, dims):
     rng = np.random.default_rng(din * 131 + dout + n)
     X = rng.standard_normal((n, din)).astype(np.float32); W = (rng.standard_normal((din, dout)) / np.sqrt(din)).astype(np.float32)
     tX, tW = to_dev(dev, X, W)
-    agg = T.forward(tX, *meta)[0]
-    want = agg.double() @ tW.double()
-    bound = agg.double().abs() @ tW.double().abs() + 1.0
+    # expected value: the ORACLE's aggregate (TF32-mode operands, as forward() rounds them) times W in fp64 - not the HIP path's own
+    # forward() (HIP against HIP).  The oracle accumulates in fp32 in its own order: its distance to the kernel's
+    # aggregate is accumulation noise relative to sum |a||x| (TIGHT), carried through |W|.
+    agg_o = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
+    _, abs_o = O.spmm_f64(X, rp, col)
+    want = torch.from_numpy(agg_o @ W.astype(np.float64)).to(dev)
+    bound = torch.from_numpy((abs_o + 1.0) @ np.abs(W.astype(np.float64)) + 1.0).to(dev)
     got = T.forward_gemm(tX, tW, *meta)[0]
     assert got.shape == (n, dout) and got.dtype == torch.float32
-    assert n == 0 or ((got.double() - want).abs() / bound).max().item() <= 4e-6
+    assert n == 0 or ((got.double() - want).abs() / bound).max().item() <= 2 * TIGHT
     got_r = T.forward_gemm(tX, tW, *meta, relu=True)[0]
-    assert n == 0 or ((got_r.double() - want.clamp(min=0)).abs() / bound).max().item() <= 4e-6
+    assert n == 0 or ((got_r.double() - want.clamp(min=0)).abs() / bound).max().item() <= 2 * TIGHT
+    # ... and the two-step form it replaces stays within the same distance
+    agg = T.forward(tX, *meta)[0]
+    assert n == 0 or ((agg.double() @ tW.double() - want).abs() / bound).max().item() <= 2 * TIGHT
     assert torch.equal(got, T.forward_gemm(tX, tW, *meta)[0])                      # deterministic
     with pytest.raises(RuntimeError, match="D_in, D_out <= 128"):
         T.forward_gemm(torch.zeros(n, 129, device=dev), torch.zeros(129, 4, device=dev), *meta)
@@ -1310,6 +1423,15 @@ def test_dense_update_on_the_lds_resident_kernel(dev, T, dims, monkeypatch):
         again = T.forward_gemm(X, W, *meta)[0]
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
+    # expected value from the oracle's aggregate (see test_dense_update_fused_behind_the_aggregation), on 512 sampled row windows
+    host = tuple(t.cpu().numpy() for t in meta)
+    wins = np.sort(np.random.default_rng(din).choice((n + 15) // 16, size=512, replace=False)).astype(np.int32)
+    rows, agg_o = O.spmm_windows(X.cpu().numpy(), *host, wins)
+    trows = torch.from_numpy(rows).to(dev)
+    assert ((agg[trows].double().cpu().numpy() - agg_o) ** 2).sum() <= 1e-8 * (agg_o.astype(np.float64) ** 2).sum()
+    want_o = torch.from_numpy(agg_o.astype(np.float64)).to(dev) @ W.double()
+    bound_o = torch.from_numpy(np.abs(agg_o).astype(np.float64)).to(dev) @ W.double().abs() + 200.0    # (+ the aggregate's own accumulation noise: ~200 terms per row)
+    assert ((got[trows].double() - want_o).abs() / bound_o).max().item() <= 2 * TIGHT
     want = agg.double() @ W.double()
     bound = agg.double().abs() @ W.double().abs() + 1.0
     assert ((got.double() - want).abs() / bound).max().item() <= 4e-6
@@ -1365,6 +1487,38 @@ def test_gcn_layer_that_aggregates_first_trains_like_the_reference_order(dev, T)
     y_two = gin(x.clone().requires_grad_(True), *meta)
     assert ((y_fused - y_two).abs() / (y_two.abs() + 10.0)).max().item() <= 1e-5
 
+
+
+def test_gin_layer_eval_and_train_forward_agree(dev, T):
+    """GINConv under no_grad takes the one-launch (A X) W of tcgnn_spmm_gemm, in training forward() + torch.mm - another
+    summation order.  The two agree within the bar at layer level, against the oracle's aggregate too, and the switch
+    (tcgnn_layers.GIN_FUSED_INFERENCE / TCGNN_GIN_FUSED_INFERENCE=0) puts eval on the training path's arithmetic bit for bit."""
+    import tcgnn_layers as L
+    for name, (rp, col), din, dout in (("sparse", graphs.uniform_graph(3000, 150, seed=2), 64, 41), ("citeseer shape", graphs.uniform_graph(3327, 2.8, seed=1), 16, 16),
+                                       ("dense enough for the LDS-resident kernel", graphs.uniform_graph(20000, 300, seed=9), 64, 64)):
+        (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+        n = len(rp) - 1
+        torch.manual_seed(3)
+        gin = L.GINConv(din, dout).to(dev)
+        gin.weights.data.mul_(din ** -0.5)
+        x = torch.randn(n, din, device=dev)
+        y_train = gin(x.clone().requires_grad_(True), *meta).detach()
+        with torch.no_grad():
+            y_eval = gin(x, *meta)
+        agg_o = O.spmm(x.cpu().numpy(), rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32).astype(np.float64)
+        want = agg_o @ gin.weights.detach().double().cpu().numpy()
+        for y in (y_train, y_eval):
+            err = np.abs(y.double().cpu().numpy() - want) / np.maximum(1.0, np.abs(want))
+            assert err.max() <= TOL, (name, err.max())
+        assert ((y_eval - y_train).abs() / (y_train.abs() + 10.0)).max().item() <= 1e-5, name
+        old = L.GIN_FUSED_INFERENCE
+        L.GIN_FUSED_INFERENCE = False
+        try:
+            with torch.no_grad():
+                assert torch.equal(gin(x, *meta), y_train), name
+        finally:
+            L.GIN_FUSED_INFERENCE = old
+        T.clear_plan_cache()
 
 
 def _device_meta(dev, T, shape, seed=0):
@@ -1428,6 +1582,7 @@ def test_full_size_reddit_shape_wide_and_fused_properties(dev, T):
     """The Reddit-sized graph again at D = 128 and through the fused AGNN pair (r1 VERDICT: not covered at full size)."""
     n, E, meta = _device_meta(dev, T, "reddit")
     _wide_agnn_properties(dev, T, n, E, meta, 128)
+    _sampled_oracle_checks(dev, T, n, E, meta, 128)
     T.clear_plan_cache()
 
 
@@ -1457,4 +1612,5 @@ def test_full_size_ogbn_products_shape_properties(dev, T):
         c.lib.tcgnn_set_spmm_mode(0)
     del X1, Y1, Ym, ones, Yd
     _wide_agnn_properties(dev, T, n, E, meta, 128)
+    _sampled_oracle_checks(dev, T, n, E, meta, 128, nwin=512)   # (50 edges per row: 512 windows = 8 192 rows, ~0.4 M edges)
     T.clear_plan_cache()

@@ -132,3 +132,31 @@ def test_csr_baseline_is_the_same_operator():
     X = np.random.default_rng(5).standard_normal((900, 24)).astype(np.float32)
     Y64, absY = O.spmm_f64(X, rp, col)
     assert np.all(np.abs(O.csr_spmm(X, rp, col, threads=2) - Y64) <= 1e-6 * (absY + 1))
+
+
+@pytest.mark.parametrize("maker", [lambda: graphs.uniform_graph(1000, 20, seed=3), lambda: graphs.powerlaw_graph(700, 12, seed=4),
+                                   lambda: graphs.uniform_graph(47, 5, seed=5)], ids=["uniform_n1000", "powerlaw_n700", "ragged_last_window_n47"])
+def test_window_list_entry_points_are_the_same_thread_block_bodies(maker):
+    """oracle_spmm_windows / oracle_sddmm_windows (what the GPU tests at BASELINE size evaluate on sampled row windows) run the
+    SAME per-window bodies as oracle_spmm / oracle_sddmm: bit-equal on the listed windows, nothing written elsewhere."""
+    rp, col = maker()
+    n = len(rp) - 1
+    bp, e2c, e2r, _ = graphs.host_sgt(rp, col)
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 24)).astype(np.float32)
+    att = rng.standard_normal(len(col)).astype(np.float32)
+    nw = (n + 15) // 16
+    wins = np.sort(rng.choice(nw, size=min(5, nw), replace=False)).astype(np.int32)
+    if nw - 1 not in wins:
+        wins = np.append(wins, np.int32(nw - 1)).astype(np.int32)     # the ragged last window
+    for mode in (O.ROUND_TF32, O.ROUND_NONE):
+        Y = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=mode); Yv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=mode)
+        ef = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=mode)
+        rows, Ys = O.spmm_windows(X, rp, col, bp, e2c, e2r, wins, round_mode=mode)
+        assert rows.max() < n and np.array_equal(Ys, Y[rows])
+        _, Yvs = O.spmm_windows(X, rp, col, bp, e2c, e2r, wins, att=att, round_mode=mode)
+        assert np.array_equal(Yvs, Yv[rows])
+        edges, efs = O.sddmm_windows(X, rp, col, bp, e2c, e2r, wins, round_mode=mode)
+        assert np.array_equal(efs, ef[edges])
+        want = np.concatenate([np.arange(rp[min(16 * w, n)], rp[min(16 * w + 16, n)]) for w in wins])
+        assert np.array_equal(edges, want)
