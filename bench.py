@@ -70,6 +70,12 @@ def parse():
                         "only (never), or exchange only when the global feature matrix does not fit one GPU (auto)")
     p.add_argument("--all-generators", action="store_true", help="also the r02 graph variants (SBM with hubs, under random ids, relabelled)")
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--plan-only", action="store_true",
+                   help="no GPU, no process group: print the per-rank memory plan of the row-sharded workload (--shape, default "
+                        "ogbn-papers100M, --dim, --gpus ranks) against 288 GB of HBM per GPU and exit")
+    p.add_argument("--shard-files", default=None,
+                   help="--plan-only: template of the shard files written by tools/convert_dataset.py --shards (\"g.rank{rank}of{world}.npz\"): rows and "
+                        "edges per rank are read from them instead of assumed even")
     return p.parse_args()
 
 
@@ -732,6 +738,83 @@ def multi_gpu(args):
     return out
 
 
+HBM_BYTES = 288 * 10 ** 9   # per MI355X (MI355X_MICROARCH.md: 288 GB HBM3E)
+XGMI_LINK_BPS = 153e9        # one xGMI link, one direction; 7 links per GPU, point-to-point
+
+
+def x16_pitch_halves(dpad):
+    """csrc x16_pitch: row pitch of the gather walks' fp16 image (power of two up to one 128-byte line, whole lines beyond)."""
+    b = dpad * 2
+    if b > 128:
+        return (b + 127) // 128 * 128 // 2
+    p = 32
+    while p < b:
+        p <<= 1
+    return p // 2
+
+
+def plan_only(args):
+    """BASELINE.json configs[4] (ogbn-papers100M GCN hidden 64 over 8 GPUs) has never met hardware here and its graph is not on
+    any box; what CAN be checked without either is that every rank's working set fits its 288 GB and what one exchange moves.
+    Per rank (tcgnn_shard.RowShard / HipShardOps, include/tcgnn.h): the local int32 CSR, the SGT metadata (blockPartition,
+    edgeToColumn, edgeToRow), the packed tile stream of the plan (per 16x32 wide block: 32 ids + 16 mask words + 16 edge offsets =
+    256 B; wide blocks from the expected number of distinct columns of a 16-row window), the fp16 image of the GATHERED matrix (the
+    kernels' workspace), the fp32 gather buffers of the exchange, and the layer tensors of the 2-layer GCN (features, hidden
+    activations, their gradients).  Rows / edges per rank come from shard files when given, else an even split."""
+    import math
+    import tcgnn_graph as G
+    shape = args.shape if args.shape != "reddit" else "ogbn-papers100M"
+    n, nnz, in_dim, classes = G.SHAPES[shape]
+    world, D = max(1, args.gpus), args.dim
+    per = []
+    if args.shard_files:
+        for r in range(world):
+            obj = np.load(args.shard_files.format(rank=r, world=world))
+            rp = obj["row_pointers"]
+            per.append((len(rp) - 1, int(rp[-1]), int(obj["H"])))
+            n = int(obj["num_nodes"])
+        nnz = sum(x[1] for x in per)
+    else:
+        rows = [((n + 15) // 16 * (r + 1) // world - (n + 15) // 16 * r // world) * 16 for r in range(world)]
+        rows[-1] -= sum(rows) - n
+        H = max(16, (max(rows) + 15) // 16 * 16)
+        per = [(rows[r], nnz // world + (1 if r < nnz % world else 0), H) for r in range(world)]
+    out_rows = []
+    for r, (rows_r, nnz_r, H) in enumerate(per):
+        ncols = H * world
+        nw = (rows_r + 15) // 16
+        k = nnz_r / max(nw, 1)                                            # edges of a window
+        distinct = ncols * (1.0 - math.exp(-k / ncols)) if ncols else 0   # expected distinct columns among them (uniform bound: real graphs condense better)
+        wide = nw * math.ceil(distinct / 32.0)
+        dpad = (D + 15) // 16 * 16
+        csr = 4 * (rows_r + 1) + 4 * nnz_r
+        sgt = 4 * nw + 8 * nnz_r
+        plan = int(wide * 256 + 8 * (nw + 1) + 4 * nw)
+        image = 256 + (ncols + 1) * x16_pitch_halves(dpad) * 2
+        gather = 4 * D * (ncols + H)                                      # recv + send of RowShard.gather (fp32)
+        widest = max(D, classes)
+        gather_all = 4 * (ncols + H) * (D + classes)                      # one buffer pair per width used (D and the class layer)
+        feats = 4 * rows_r * in_dim
+        acts = 4 * rows_r * (2 * D + 2 * classes) * 2                     # X W, A(X W) per layer, and their gradients
+        image_w = 256 + (ncols + 1) * x16_pitch_halves((widest + 15) // 16 * 16) * 2
+        total = csr + sgt + plan + image_w + gather_all + feats + acts
+        out_rows.append({"rank": r, "rows": rows_r, "edges": nnz_r, "gathered_rows": ncols, "csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan,
+                         "image_fp16_bytes": image, "gather_buffer_bytes": gather, "features_bytes": feats, "layer_tensors_bytes": acts,
+                         "total_bytes": total, "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES})
+    H = per[0][2]
+    blk32, blk16 = 4 * H * D, 2 * H * x16_pitch_halves((D + 15) // 16 * 16)
+    doc = {"plan_only": True, "workload": "%s GCN hidden=%d, rows sharded over %d GPUs (BASELINE.json configs[4])" % (shape, D, world),
+           "nodes": n, "edges": nnz, "world": world, "D": D, "hbm_bytes_per_gpu": HBM_BYTES, "all_fit": all(r["fits"] for r in out_rows),
+           "max_frac_of_hbm": max(r["frac_of_hbm"] for r in out_rows),
+           "int32_csr_possible_unsharded": nnz < 2 ** 31,
+           "exchange_per_spmm": {"fp32_block_bytes": blk32, "fp16_block_bytes": blk16,
+                                 # every GPU pushes its block to its (world - 1) peers at once, one xGMI link each (SURVEY.md 8e)
+                                 "fp32_ms_link_bound": round(blk32 / XGMI_LINK_BPS * 1e3, 2) if world > 1 else 0.0,
+                                 "fp16_ms_link_bound": round(blk16 / XGMI_LINK_BPS * 1e3, 2) if world > 1 else 0.0},
+           "source": args.shard_files or "even split of the published node / symmetrised edge counts (SURVEY.md 8a)", "per_rank": out_rows}
+    return doc
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves (torch.distributed.run, rendezvous on
     127.0.0.1 at a free port) with the same arguments; rank 0 of that job prints the JSON line, last, on the stdout we share
@@ -843,6 +926,9 @@ def write_detail(out):
 
 def main():
     args = parse()
+    if args.plan_only:
+        print(json.dumps(plan_only(args)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("TCGNN_BENCH_FORCE_SHARDED"):   # (the env switch runs the sharded path with a world of 1)
         if "RANK" not in os.environ:

@@ -73,6 +73,9 @@ SHAPES = {  # name: (N, nnz target, in_dim, classes) - SURVEY.md 8(d)
     "pubmed": (19717, 88648, 500, 3),
     "reddit": (232965, 114615892, 602, 41),
     "ogbn-products": (2449029, 123718280, 100, 47),
+    # BASELINE.json configs[4]: symmetrised edge count; never built as ONE CSR (3.23 G > 2^31: row shards only -
+    # tools/convert_dataset.py --shards, tcgnn_shard.RowShard.from_shard_file, bench.py --plan-only)
+    "ogbn-papers100M": (111059956, 3231371744, 128, 172),
     # The reference's artifact graphs (1_bench_gcn.py / 2_tcgnn_single_kernel.py dataset lists give dim and classes;
     # the .npz files are not in the tree).  N and nnz are the node / edge counts of the TC-GNN paper's dataset table,
     # used for same-SIZE synthetic stand-ins (tools/bench_artifact_shapes.py) - real graphs have more locality.

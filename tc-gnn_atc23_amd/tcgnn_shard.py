@@ -224,8 +224,27 @@ class _GatherSpmm(torch.autograd.Function):
 class RowShard:
     """One rank's share of a graph plus the exchange step."""
 
+    @classmethod
+    def from_shard_file(cls, path, rank=None, world_size=None, device=None, group=None, ops_factory=None, always_collective=None):
+        """This rank's shard from a file written by `tools/convert_dataset.py --shards P` (BASELINE.json configs[4]: a graph whose
+        3.23 G edges cannot exist as one int32 CSR is never materialised whole - dataset.py:94-104 is the single-process form this
+        replaces).  `path` is the rank's own file or a template with {rank} / {world} fields ("papers.rank{rank}of{world}.npz").
+        The file holds local int32 row pointers, column ids already in the padded-gather numbering, and the global boundaries."""
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world_size is None else world_size
+        obj = np.load(path.format(rank=rank, world=world))
+        if int(obj["rank"]) != rank or int(obj["world"]) != world:
+            raise ValueError("%s is shard %d of %d, this process is rank %d of %d" % (path, int(obj["rank"]), int(obj["world"]), rank, world))
+        bounds = [int(x) for x in obj["bounds"]]
+        shard = cls(rank=rank, world_size=world, device=device, group=group, ops_factory=ops_factory, bounds=bounds,
+                    local=(obj["row_pointers"], obj["column_index"]), always_collective=always_collective, local_is_remapped=True)
+        if shard.layout.H != int(obj["H"]):
+            raise ValueError("%s was written for gather blocks of %d rows, the layout of its boundaries has %d" % (path, int(obj["H"]), shard.layout.H))
+        shard.num_nodes_global = int(obj["num_nodes"])
+        return shard
+
     def __init__(self, row_pointers=None, column_index=None, rank=None, world_size=None, device=None, group=None,
-                 ops_factory=None, bounds=None, local=None, always_collective=None):
+                 ops_factory=None, bounds=None, local=None, always_collective=None, local_is_remapped=False):
         """Either the whole CSR (row_pointers, column_index; every rank holds it or builds it the
         same way) or `local=(local_row_pointers, global_column_ids)` + `bounds` when each rank only
         ever materialises its own rows (graphs too large for one host/GPU)."""
@@ -241,7 +260,7 @@ class RowShard:
             assert bounds is not None, "local shards need the global row boundaries"
             self.layout = ShardLayout(bounds)
             lrp = np.ascontiguousarray(local[0], dtype=np.int32)
-            lcol = self.layout.remap(local[1])
+            lcol = np.ascontiguousarray(local[1], dtype=np.int32) if local_is_remapped else self.layout.remap(local[1])
         else:
             bounds = bounds if bounds is not None else partition_rows(row_pointers, self.world)
             self.layout = ShardLayout(bounds)

@@ -82,3 +82,37 @@ def test_detail_file_holds_everything(tmp_path, monkeypatch):
     assert written == ["bench_detail.json"]
     with open(tmp_path / "bench_detail.json") as f:
         assert json.load(f) == full
+
+
+def test_plan_only_prints_the_per_rank_memory_plan_of_config_5(tmp_path):
+    """`python bench.py --gpus 8 --plan-only`: no GPU, no process group - the per-rank bytes of the
+    ogbn-papers100M workload (BASELINE.json configs[4]) against 288 GB, and what one exchange moves."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plan-only"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    doc = json.loads(r.stdout.strip().splitlines()[-1])
+    assert doc["plan_only"] and doc["world"] == 8 and doc["nodes"] == 111059956 and doc["edges"] == 3231371744
+    assert doc["int32_csr_possible_unsharded"] is False            # why the shard loader exists
+    assert len(doc["per_rank"]) == 8 and doc["all_fit"] and 0.05 < doc["max_frac_of_hbm"] < 1.0
+    assert sum(x["rows"] for x in doc["per_rank"]) == doc["nodes"] and sum(x["edges"] for x in doc["per_rank"]) == doc["edges"]
+    for x in doc["per_rank"]:
+        assert x["edges"] < 2 ** 31 and x["rows"] % 16 == 0 or x["rank"] == 7
+        parts = ("csr_bytes", "sgt_metadata_bytes", "plan_bytes_est", "features_bytes", "layer_tensors_bytes")
+        assert x["total_bytes"] > sum(x[k] for k in parts) and x["total_bytes"] < doc["hbm_bytes_per_gpu"]
+        assert x["image_fp16_bytes"] == 256 + (x["gathered_rows"] + 1) * 128          # D = 64: one 128-byte line per row
+    ex = doc["exchange_per_spmm"]
+    assert ex["fp16_block_bytes"] * 2 == ex["fp32_block_bytes"] and 20 < ex["fp32_ms_link_bound"] < 26    # SURVEY.md 8e: ~23 ms fp32, ~12 ms fp16
+    # with shard files: rows and edges per rank are the files'
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import convert_dataset as C
+    import numpy as np
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 5000, 60000); d = rng.integers(0, 5000, 60000)
+    np.savez(tmp_path / "ei.npz", edge_index=np.stack([s, d]), num_nodes=np.array(5000))
+    written = C.convert_sharded(str(tmp_path / "ei.npz"), str(tmp_path / "g"), 4, symmetrize=True, drop_self_loops=True, tmp=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plan-only", "--shard-files", str(tmp_path / "g.rank{rank}of{world}.npz")],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 0, r.stderr[-2000:]
+    doc = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [x["rows"] for x in doc["per_rank"]] == [w[1] for w in written] and [x["edges"] for x in doc["per_rank"]] == [w[2] for w in written]

@@ -216,3 +216,149 @@ def test_a_world_of_one_can_still_issue_the_collectives(tmp_path):
         assert b.gather(X).shape[0] == b.layout.num_cols and torch.equal(a.spmm(X), b.spmm(X)) and torch.equal(a.sddmm(X), b.sddmm(X))
     finally:
         dist.destroy_process_group()
+
+
+# ---- config 5 (ogbn-papers100M pattern): shard files written by tools/convert_dataset.py --shards, loaded per rank ----------------
+
+def _raw_pairs(seed=9, n=900, e=14000):
+    """A directed int64 pair list with duplicates and self loops, as a dataset file would hold it (OGB stores each undirected
+    edge once: the converter symmetrises)."""
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, n, e); d = (s + rng.geometric(0.02, e)) % n
+    s[:50] = d[:50]                                  # self loops
+    s = np.concatenate([s, s[:300]]); d = np.concatenate([d, d[:300]])    # duplicates
+    return s.astype(np.int64), d.astype(np.int64), n
+
+
+def _global_csr(s, d, n, symmetrize=True, drop_self_loops=True):
+    from scipy.sparse import coo_matrix
+    if drop_self_loops:
+        keep = s != d
+        s, d = s[keep], d[keep]
+    if symmetrize:
+        s, d = np.concatenate([s, d]), np.concatenate([d, s])
+    m = coo_matrix((np.ones(len(s), np.int8), (s, d)), shape=(n, n)).tocsr()      # dataset.py:94-99: duplicates merged, columns sorted
+    m.sum_duplicates(); m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32)
+
+
+@pytest.mark.parametrize("shards,chunk", [(1, 1 << 20), (2, 777), (3, 4096), (8, 100000)])
+def test_sharded_conversion_equals_slices_of_the_global_csr(tmp_path, shards, chunk):
+    """tools/convert_dataset.py --shards P streams the pair list and never builds the global CSR; every rank's file must equal
+    the slice tcgnn_shard.local_csr cuts from the global one (rows, column ids in the gathered numbering, boundaries)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import convert_dataset as C
+    import tcgnn_shard as S
+    s, d, n = _raw_pairs()
+    src = tmp_path / "edge_index.npz"
+    np.savez(src, edge_index=np.stack([s, d]), num_nodes_list=np.array([n]))          # OGB's data.npz form (uncompressed: memory-mapped)
+    written = C.convert_sharded(str(src), str(tmp_path / "g"), shards, symmetrize=True, drop_self_loops=True, chunk=chunk, tmp=str(tmp_path))
+    rp, col = _global_csr(s, d, n)
+    # the balance is computed on RAW degrees (duplicates included), the reference partition on merged ones: same rule, so compare
+    # against local_csr under the FILE's boundaries, and check those are window-aligned, monotone and near-balanced
+    obj0 = np.load(written[0][0])
+    bounds = [int(x) for x in obj0["bounds"]]
+    assert bounds[0] == 0 and bounds[-1] == n and all(b % 16 == 0 for b in bounds[:-1]) and all(x <= y for x, y in zip(bounds, bounds[1:]))
+    lay = S.ShardLayout(bounds)
+    total = 0
+    for p, (name, rows, nnz) in enumerate(written):
+        obj = np.load(name)
+        lrp, lcol = S.local_csr(rp, col, lay, p)
+        assert int(obj["rank"]) == p and int(obj["world"]) == shards and int(obj["num_nodes"]) == n and int(obj["H"]) == lay.H
+        assert obj["row_pointers"].dtype == np.int32 and obj["column_index"].dtype == np.int32
+        assert np.array_equal(obj["row_pointers"], lrp) and np.array_equal(obj["column_index"], lcol)
+        assert rows == len(lrp) - 1 and nnz == len(lcol)
+        total += nnz
+    assert total == len(col)
+    nnz = [w[2] for w in written]
+    heaviest = max(int(rp[min(w + 16, n)] - rp[w]) for w in range(0, n, 16))
+    assert shards == 1 or max(nnz) - min(nnz) <= 4 * heaviest + 600     # (raw-degree balance: the 300 duplicated pairs may shift a boundary)
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("tcgnn_shards_")]    # spill files removed
+
+
+def test_sharded_conversion_of_a_compressed_or_text_source(tmp_path):
+    """Containers that cannot be memory-mapped (np.savez_compressed, SNAP text) go through their readers and are sliced."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import convert_dataset as C
+    s, d, n = _raw_pairs(seed=3, n=200, e=1500)
+    a = tmp_path / "z.npz"; np.savez_compressed(a, edge_index=np.stack([s, d]), num_nodes=np.array(n))
+    b = tmp_path / "edges.txt"
+    with open(b, "w") as f:
+        f.write("# comment\n" + "".join("%d %d\n" % (x, y) for x, y in zip(s, d)))
+    wa = C.convert_sharded(str(a), str(tmp_path / "a"), 2, chunk=500, tmp=str(tmp_path))
+    wb = C.convert_sharded(str(b), str(tmp_path / "b"), 2, chunk=500, tmp=str(tmp_path))
+    rp, col = _global_csr(s, d, n, symmetrize=False, drop_self_loops=False)
+    assert sum(w[2] for w in wa) == len(col)
+    # (the text file carries no node count: max id + 1, dataset.py:61 - the last nodes may be missing, the edges are the same)
+    for (fa, _, _), (fb, _, _) in zip(wa, wb):
+        oa, ob = np.load(fa), np.load(fb)
+        if int(ob["num_nodes"]) == n:
+            assert np.array_equal(oa["row_pointers"], ob["row_pointers"]) and np.array_equal(oa["column_index"], ob["column_index"])
+    assert C.main([str(a), str(tmp_path / "cli"), "--shards", "2", "--tmp", str(tmp_path)]) == 0
+
+
+def _file_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tc-gnn_atc23_amd"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import tcgnn_shard as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, d, n = _raw_pairs()
+        rp, col = _global_csr(s, d, n)
+        D = 24
+        X = np.random.default_rng(0).standard_normal((n, D)).astype(np.float32)
+        # the sharded-file path: this rank reads ONLY its own file
+        fshard = S.RowShard.from_shard_file(os.path.join(out_dir, "g.rank{rank}of{world}.npz"), ops_factory=OracleShardOps)
+        # the in-memory path under the same boundaries
+        mshard = S.RowShard(rp, col, ops_factory=OracleShardOps, bounds=fshard.layout.bounds)
+        b0, b1 = fshard.layout.bounds[rank], fshard.layout.bounds[rank + 1]
+        x_local = torch.from_numpy(X[b0:b1])
+        bp = np.zeros((n + 15) // 16, np.int32); e2c = np.zeros(len(col), np.int32); e2r = np.zeros(len(col), np.int32)
+        O.preprocess(col, rp, n, 16, 8, bp, e2c, e2r)
+        Yfull = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_NONE)
+        ok = {"same_rows": np.array_equal(fshard.local_row_pointers, mshard.local_row_pointers),
+              "same_cols": np.array_equal(fshard.local_column_index, mshard.local_column_index),
+              "same_layout": fshard.layout.H == mshard.layout.H and fshard.num_nodes_global == n,
+              "spmm_equal": torch.equal(fshard.spmm(x_local), mshard.spmm(x_local)),
+              "spmm_vs_single_process": np.allclose(fshard.spmm(x_local).numpy(), Yfull[b0:b1], atol=1e-5),
+              "sddmm_equal": torch.equal(fshard.sddmm(x_local), mshard.sddmm(x_local))}
+        try:   # a file of another rank is refused
+            S.RowShard.from_shard_file(os.path.join(out_dir, "g.rank%dof%d.npz" % (1 - rank, world)), ops_factory=OracleShardOps)
+            ok["wrong_file_refused"] = False
+        except ValueError:
+            ok["wrong_file_refused"] = True
+        np.save(os.path.join(out_dir, "frank%d.npy" % rank), np.array([int(v) for v in ok.values()]))
+        with open(os.path.join(out_dir, "frank%d.txt" % rank), "w") as f:
+            f.write(repr(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_load_their_shard_files_and_match_the_in_memory_path(tmp_path):
+    """RowShard.from_shard_file never materialises the global CSR; world 2 over gloo, each rank opening its
+    own file, equals the in-memory path (same rows, same columns, same products) and the single-process result."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import convert_dataset as C
+    s, d, n = _raw_pairs()
+    src = tmp_path / "edge_index.npy"
+    np.save(src, np.stack([s, d]))
+    C.convert_sharded(str(src), str(tmp_path / "g"), 2, fmt="edge-index", symmetrize=True, drop_self_loops=True, chunk=3000, tmp=str(tmp_path))
+    # (a .npy carries no node count: max id + 1; make sure the last node has an edge so that it equals n)
+    assert int(np.load(tmp_path / "g.rank0of2.npz")["num_nodes"]) <= n
+    if int(np.load(tmp_path / "g.rank0of2.npz")["num_nodes"]) != n:
+        np.savez(tmp_path / "ei.npz", edge_index=np.stack([s, d]), num_nodes=np.array(n))
+        C.convert_sharded(str(tmp_path / "ei.npz"), str(tmp_path / "g"), 2, symmetrize=True, drop_self_loops=True, chunk=3000, tmp=str(tmp_path))
+    port = _free_port()
+    mp.spawn(_file_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        flags = np.load(tmp_path / ("frank%d.npy" % r))
+        assert flags.all(), open(tmp_path / ("frank%d.txt" % r)).read()
