@@ -619,6 +619,7 @@ def cpu_baseline(rp, col, n, E, D, seed):
 
 def multi_gpu(args):
     import tcgnn_graph as G
+    import tcgnn_harness as H
     import tcgnn_shard as S
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
@@ -695,7 +696,7 @@ def multi_gpu(args):
         feats = torch.randn(n0, in_dim, device=dev, generator=g)
         labels = torch.ones(n0, dtype=torch.long, device=dev)
         model = S.ShardedGCN(in_dim, D, classes, num_layers=2, seed=args.seed).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        opt = H.make_adam(model.parameters())
         ep = lambda: S.sharded_train_step(model, shard, feats, labels, opt, n_global)
         gcn_ms = sync_time(ep, max(2, args.epochs // 2), 3, barrier) * 1e3 / max(2, args.epochs // 2)
         del feats, model, opt

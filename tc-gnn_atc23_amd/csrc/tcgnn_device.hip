@@ -107,8 +107,21 @@ struct tcgnn_plan {
         uint32_t* d_flat = nullptr;        // [npairs][16 wavefronts][32 * maxw * flat_tpc words] metadata blocks
         int32_t* d_wcold_ptr = nullptr;    // [nwg * 16 + 1] the cold remainder as per-wavefront record lists, multiplied inside the flat kernel
         uint32_t* d_wcold = nullptr;       // [cold tiles][64 words] 32 column ids, 16 mask words, window slot (layouts with LDS to spare)
+        // single-edge streams only (slot 6): CSR position of the edge in every K slot of the flat stream / of the cold tiles, -1: none
+        int32_t* d_eidx = nullptr;         // [tiles][32], tile (pair k, wavefront v, entry x) = (k * 16 + v) * maxw * flat_tpc + x  (build time only)
+        int32_t* d_cold_eidx = nullptr;    // [cold_tiles][32]                                                                          (build time only)
+        uint16_t* d_eidx16 = nullptr;      // the same as offsets from the window's first CSR edge, 0xffff: none (what val_permute_kernel reads)
+        uint16_t* d_cold_eidx16 = nullptr;
     };
-    CellStream lds[6];   // (kLdsStreams)
+    CellStream lds[7];   // (kLdsStreams; slot 6: the single-edge stream of the edge-valued LDS-resident SpMM, tcgnn_lds_val.inc)
+    // single-edge tile stream (built with slot 6, on the first edge-valued call that would use it): every condensed column repeated
+    // once per edge, so a K slot of a tile carries exactly ONE edge and a per-call value array can sit beside the slots
+    int64_t* d_xwb_ptr = nullptr;   // [nw_eff + 1]
+    int32_t* d_xcols = nullptr;     // [total_xwb][32]
+    uint32_t* d_xmask = nullptr;    // [total_xwb][16] one bit per column
+    int32_t* d_xeidx = nullptr;     // [total_xwb][32] CSR position of the slot's edge, -1: none
+    int64_t total_xwb = 0;
+    std::atomic<int8_t> val_choice{-1};   // -1 not tried, 0 the single-edge stream is of no use here (gather walks), 1 built
     mutable std::atomic<int8_t> lds_choice[65];   // automatic mode, per padded width / 16: -1 not decided yet, 0 gather walks, 1 LDS-resident kernel
     tcgnn_plan() { for (auto& c : lds_choice) c.store(-1, std::memory_order_relaxed); }
     // optional kernel timing (tcgnn_plan_set_timing): event pairs around the main kernel launches; slots are claimed atomically
@@ -1040,6 +1053,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(co
 
 #include "tcgnn_lds_spmm.inc"
 #include "tcgnn_lds_flat.inc"
+#include "tcgnn_lds_val.inc"
 
 // ------------------------------------------------------------------------------------------
 // SDDMM:  ef[e] = <X16[row e], X16[col e]>
@@ -2686,6 +2700,15 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     std::lock_guard<std::mutex> lock(mu);
     if (p->lds[slot].nranges > 0) return TCGNN_OK;
     if (p->nw_eff <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
+    // the stream is cut from the packed tile stream (cols / mask) or, slot kLdsValSlot, from the single-edge one, whose K slots also
+    // carry the CSR position of their edge: that index follows every slot into the tiles (s_eidx / d_eidx)
+    const bool val = slot == kLdsValSlot;
+    if (val && !p->d_xwb_ptr) return fail(TCGNN_ERR_INVALID_ARG, "edge-valued LDS-resident SpMM: the single-edge stream has not been built");
+    const int64_t* const s_wb = val ? p->d_xwb_ptr : p->d_wb_ptr;
+    const int32_t* const s_cols = val ? p->d_xcols : p->d_cols;
+    const uint32_t* const s_mask = val ? p->d_xmask : p->d_mask;
+    const int32_t* const s_eidx = val ? p->d_xeidx : nullptr;
+    int32_t *d_eidx = nullptr, *d_cold_eidx = nullptr;
     const int maxw = lds_stream_maxw(slot);
     const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
     const int nranges = (p->Nc + rows - 1) / rows;
@@ -2706,7 +2729,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         if (e0 == hipSuccess) e0 = hipMemsetAsync(d_wt, 0, h_wt.size() * sizeof(uint32_t), stream);
         if (e0 == hipSuccess) {
             const int64_t nth = (int64_t)p->nw_eff * nranges;
-            hipLaunchKernelGGL(window_tiles_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, p->nw_eff, nranges, p->Nc, rows, d_wt);
+            hipLaunchKernelGGL(window_tiles_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, stream, s_wb, s_cols, p->nw_eff, nranges, p->Nc, rows, d_wt);
             e0 = hipGetLastError();
         }
         if (e0 == hipSuccess) e0 = hipMemcpyAsync(h_wt.data(), d_wt, h_wt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -2764,7 +2787,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
         c.pairtiles.resize((size_t)npairs_all);
         if (e == hipSuccess) {
             const int64_t nthreads = (int64_t)nw * nranges;
-            hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, c.d_sorder, p->d_cols, nw, nwg,
+            hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, s_wb, c.d_sorder, s_cols, nw, nwg,
                                nranges, p->Nc, maxw, rows, c.d_cellcols, c.d_firstq, c.d_parts);
             hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, c.d_cellcols, npairs_all, per_wg, maxw, d_pc, d_pm, d_po, d_pt);
             e = hipGetLastError();
@@ -2832,7 +2855,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     uint32_t* d_flat = nullptr;
     auto bail2 = [&](int rc) {
         (void)hipFree(d_flat); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_rbase); (void)hipFree(d_rlist); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
-        (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask);
+        (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask); (void)hipFree(d_eidx); (void)hipFree(d_cold_eidx);
         return bail(rc);
     };
     e = hipMalloc(&d_kmap, (size_t)npairs_all * sizeof(int32_t));
@@ -2913,6 +2936,8 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
             flat_tpc = 0; over_cols = 0;
         }
     }
+    if (val && flat_tpc != 1)   // (spmm_lds_val_kernel walks flat streams with one tile per cell only; the caller keeps the gather walks)
+        return bail2(fail(TCGNN_ERR_UNSUPPORTED, "edge-valued LDS-resident SpMM: the single-edge cells of this graph are not uniform enough for a flat stream"));
     hot_cols -= over_cols; cold_cols += over_cols;
     if (ncell > 0) hipLaunchKernelGGL(cell_compact_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, npairs_all, per_wg, d_cnt);
     std::vector<uint32_t> cnt((size_t)ncell_hot + 1);
@@ -2930,9 +2955,14 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
     hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
-    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, nwg, nranges, p->Nc,
-                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols, flat_tpc);
-    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows);
+    if (val) {   // (flat only: the caller gives the stream up otherwise)
+        e = hipMalloc(&d_eidx, (size_t)std::max<int64_t>(ntiles, 1) * 32 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_eidx, 0xff, (size_t)std::max<int64_t>(ntiles, 1) * 32 * sizeof(int32_t), stream);
+        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "edge index of the cell stream: %s", hipGetErrorString(e)));
+    }
+    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, s_wb, d_sorder, s_cols, s_mask, nwg, nranges, p->Nc,
+                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols, flat_tpc, s_eidx, d_eidx);
+    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows, d_eidx);
     e = hipGetLastError();
     if (e == hipSuccess && flat_tpc) {   // tiles -> per-(pair, wavefront) metadata blocks; the ordinary tiles and the cell table go
         e = hipMalloc(&d_flat, (size_t)nwords * sizeof(uint32_t));
@@ -2976,9 +3006,13 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
             e = hipMemcpyAsync(d_ccols, fillv.data(), b_c, hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
         }
+        if (e == hipSuccess && val) {
+            e = hipMalloc(&d_cold_eidx, (size_t)std::max<int64_t>(cold_tiles, 1) * 32 * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMemsetAsync(d_cold_eidx, 0xff, (size_t)std::max<int64_t>(cold_tiles, 1) * 32 * sizeof(int32_t), stream);
+        }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, d_sorder, p->d_cols, p->d_mask, d_kmap, nranges, p->Nc,
-                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts, d_firstq, (uint32_t)(32 * flat_tpc));
+            hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, s_wb, d_sorder, s_cols, s_mask, d_kmap, nranges, p->Nc,
+                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts, d_firstq, (uint32_t)(32 * flat_tpc), s_eidx, d_cold_eidx);
             e = hipGetLastError();
         }
         cold_bytes = b_ptr + b_c + b_m;
@@ -2988,7 +3022,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     int32_t* d_wcold_ptr = nullptr;
     uint32_t *d_wcold = nullptr, *d_wlist = nullptr;
     static const int wcold_enabled = [] { const char* en = getenv("TCGNN_LDS_COLD_INSIDE"); return en ? atoi(en) : 1; }();
-    if (e == hipSuccess && flat_tpc && cold_tiles > 0 && cold_tiles < (1ll << 28) && wcold_enabled && flat_cold_fits(lds_stream_nt(slot), maxw, flat_tpc)) {
+    if (e == hipSuccess && !val && flat_tpc && cold_tiles > 0 && cold_tiles < (1ll << 28) && wcold_enabled && flat_cold_fits(lds_stream_nt(slot), maxw, flat_tpc)) {
         std::vector<int32_t> wptr((size_t)nwg * kLdsWaves + 1, 0);
         std::vector<uint32_t> wlist;
         wlist.reserve((size_t)cold_tiles);
@@ -3025,6 +3059,7 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
     cs.flat_tpc = flat_tpc; cs.d_flat = d_flat;
     cs.d_wcold_ptr = d_wcold_ptr; cs.d_wcold = d_wcold;
+    cs.d_eidx = d_eidx; cs.d_cold_eidx = d_cold_eidx;
     cs.nwg = nwg; cs.tiles = ntiles;
     cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
     cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols; cs.cold_max = cold_max;
@@ -3041,9 +3076,108 @@ static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
     if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
     cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
     p->bytes += (flat_tpc ? 0 : (size_t)(ncell_hot + 1) * sizeof(uint32_t)) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
-                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes + (nsplit ? sparts.size() * sizeof(uint32_t) : 0);
+                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes + (nsplit ? sparts.size() * sizeof(uint32_t) : 0) +
+                (val ? (size_t)(std::max<int64_t>(ntiles, 1) + (cold_tiles > 0 ? cold_tiles : 0)) * 32 * sizeof(int32_t) : 0);
     cs.nranges = nranges;
     return TCGNN_OK;
+}
+
+// ---- the edge-valued LDS-resident walk (tcgnn_lds_val.inc): single-edge tile stream + its flat cell stream (slot kLdsValSlot).
+// Built on the first edge-valued call that would use it (allocates and synchronises: never inside a graph capture); the answer -
+// usable or not - is remembered in plan->val_choice.
+static int build_val_stream(tcgnn_plan* p, hipStream_t stream) {
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (p->val_choice.load(std::memory_order_acquire) >= 0) return TCGNN_OK;
+        if (!p->d_xwb_ptr) {
+            const int nw = p->nw_eff;
+            int32_t *d_ew = nullptr, *d_flags = nullptr;
+            std::vector<int32_t> ew((size_t)nw, 0);
+            hipError_t e = hipMalloc(&d_ew, (size_t)nw * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&d_flags, sizeof(int32_t));
+            if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(int32_t), stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(window_edges_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, p->rowptr, p->N, nw, d_ew);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(ew.data(), d_ew, (size_t)nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            (void)hipFree(d_ew);
+            std::vector<int64_t> xptr((size_t)nw + 1, 0);
+            for (int w = 0; w < nw; ++w) xptr[(size_t)w + 1] = xptr[(size_t)w] + (ew[(size_t)w] + kWbCols - 1) / kWbCols;
+            const int64_t total = std::max<int64_t>(xptr[(size_t)nw], 1);
+            int64_t* d_xp = nullptr; int32_t *d_xc = nullptr, *d_xe = nullptr; uint32_t* d_xm = nullptr;
+            auto drop = [&]() { (void)hipFree(d_xp); (void)hipFree(d_xc); (void)hipFree(d_xe); (void)hipFree(d_xm); (void)hipFree(d_flags); };
+            if (e == hipSuccess) e = hipMalloc(&d_xp, xptr.size() * sizeof(int64_t));
+            if (e == hipSuccess) e = hipMalloc(&d_xc, (size_t)total * kWbCols * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&d_xe, (size_t)total * kWbCols * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&d_xm, (size_t)total * kWinRows * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpyAsync(d_xp, xptr.data(), xptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_xe, 0xff, (size_t)total * kWbCols * sizeof(int32_t), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_xm, 0, (size_t)total * kWinRows * sizeof(uint32_t), stream);
+            if (e == hipSuccess) {
+                std::vector<int32_t> fillv((size_t)total * kWbCols, p->Nc);   // (padding slots point at the all-zero sentinel row, like pack_kernel's)
+                e = hipMemcpyAsync(d_xc, fillv.data(), fillv.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            }
+            int32_t bad = 0;
+            if (e == hipSuccess && nw > 0) {
+                hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, p->d_mask, p->d_ebase, d_xp, d_xc, d_xm, d_xe, p->Nc, d_flags);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess || bad) {
+                drop();
+                p->val_choice.store(0, std::memory_order_release);
+                return e == hipSuccess ? TCGNN_OK : fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "single-edge tile stream: %s", hipGetErrorString(e));
+            }
+            (void)hipFree(d_flags);
+            p->d_xwb_ptr = d_xp; p->d_xcols = d_xc; p->d_xmask = d_xm; p->d_xeidx = d_xe; p->total_xwb = xptr[(size_t)nw];
+            p->bytes += xptr.size() * sizeof(int64_t) + (size_t)total * (2 * kWbCols * sizeof(int32_t) + kWinRows * sizeof(uint32_t));
+        }
+    }
+    const int rc = build_lds_cells(p, stream, kLdsValSlot);
+    tcgnn_plan::CellStream& cs = p->lds[kLdsValSlot];
+    bool ok = rc == TCGNN_OK && cs.nranges > 0 && cs.flat_tpc == 1 && cs.nsplit == 0 && cs.d_eidx;
+    if (ok) {   // CSR positions -> 16-bit offsets into each window's run of edges (half the index bytes per call and in the plan)
+        const size_t nt = (size_t)std::max<int64_t>(cs.tiles, 1), nc = (size_t)std::max<int64_t>(cs.cold_tiles, 1);
+        int32_t* d_bad = nullptr; int32_t bad = 0;
+        hipError_t e = hipMalloc(&cs.d_eidx16, nt * 32 * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc(&cs.d_cold_eidx16, nc * 32 * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(cs.d_eidx16, 0xff, nt * 32 * sizeof(uint16_t), stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(val_index16_kernel, dim3((unsigned)(cs.nwg * kLdsWaves * kLdsMaxW2)), dim3(256), 0, stream, p->rowptr, cs.d_order, cs.d_eidx, cs.d_rbase, cs.d_eidx16, p->N,
+                               kLdsMaxW2, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx, cs.d_cold_eidx16, d_bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_bad);
+        ok = e == hipSuccess && !bad;
+        if (ok) p->bytes += (nt + nc) * 32 * sizeof(uint16_t);
+    }
+    if (cs.d_eidx) {
+        (void)hipStreamSynchronize(stream);
+        p->bytes -= (size_t)(std::max<int64_t>(cs.tiles, 1) + (cs.cold_tiles > 0 ? cs.cold_tiles : 0)) * 32 * sizeof(int32_t);
+        (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); cs.d_eidx = nullptr; cs.d_cold_eidx = nullptr;
+    }
+    // (the single-edge source is only needed to cut the cell stream: 0.9 GB on the Reddit shape, released here)
+    (void)hipStreamSynchronize(stream);
+    p->bytes -= ((size_t)p->nw_eff + 1) * sizeof(int64_t) + (size_t)std::max<int64_t>(p->total_xwb, 1) * (2 * kWbCols * sizeof(int32_t) + kWinRows * sizeof(uint32_t));
+    (void)hipFree(p->d_xwb_ptr); (void)hipFree(p->d_xcols); (void)hipFree(p->d_xmask); (void)hipFree(p->d_xeidx);
+    p->d_xwb_ptr = nullptr; p->d_xcols = nullptr; p->d_xmask = nullptr; p->d_xeidx = nullptr;
+    p->val_choice.store(ok ? 1 : 0, std::memory_order_release);
+    return (rc == TCGNN_ERR_OOM || rc == TCGNN_ERR_HIP) ? rc : TCGNN_OK;
+}
+// bytes the per-call slot values take behind the planar image (the stream's tiles and its cold tiles, 64 bytes each)
+static size_t val_stream_bytes(const tcgnn_plan* p) {
+    const tcgnn_plan::CellStream& cs = p->lds[kLdsValSlot];
+    if (p->val_choice.load(std::memory_order_acquire) != 1) return 0;
+    return ((size_t)(std::max<int64_t>(cs.tiles, 1) + std::max<int64_t>(cs.cold_tiles, 0)) * 64 + 255) / 256 * 256;
 }
 
 // columns one gather-walk launch may cover: the widest row whose pitch the structured descriptor can express, in whole
@@ -3159,13 +3293,32 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         return TCGNN_OK;
     }
+    // ---- edge values on the LDS-resident flat walk (r04, tcgnn_lds_val.inc): whole 64-column chunks, on graphs the binary SpMM's
+    //      time model sends to the LDS-resident kernel, canonical CSR (the single-edge stream is cut with the packed edge offsets).
+    //      The first such call builds the stream (unless it is being captured into a graph) and still takes a gather walk - its
+    //      workspace was sized before the stream existed; later calls find tcgnn_workspace_bytes grown by the slot values.
+    bool val_lds = false;
+    {
+        const int dp = round_up(D, 16);
+        if (d_val && !d_staged && !block_of_wider && !d_gate && !relu && !d_W && (mode == 0 || mode == 3) && dp % 64 == 0 && dp <= 2 * kMaxChunkDims && plan->canonical &&
+            plan->nw_eff > 0 && (int64_t)(dp / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32) && (mode == 3 || lds_chosen(plan, dp))) {
+            if (plan->val_choice.load(std::memory_order_acquire) < 0) {
+                hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+                if (!(hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)) {
+                    const int b = build_val_stream(const_cast<tcgnn_plan*>(plan), stream);
+                    if (b) return b;
+                }
+            }
+            val_lds = plan->val_choice.load(std::memory_order_acquire) == 1 && ws_bytes >= workspace_bytes_for(plan->Nc, D) + val_stream_bytes(plan);
+        }
+    }
     if (d_staged) {   // the caller built the (row-major) fp16 image itself: tcgnn_spmm_staged
         hdr = static_cast<const uint32_t*>(d_staged);
         x16 = reinterpret_cast<const _Float16*>(static_cast<const char*>(d_staged) + kHdrBytes);
         dpad = round_up(D, 16);
         pitch = x16_pitch(dpad);
     } else {
-        const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds, d_gate, block_of_wider ? ld : 0, block_of_wider);
+        const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds || val_lds, d_gate, block_of_wider ? ld : 0, block_of_wider);
         if (rc) return rc;
     }
     if (plan->nw_eff == 0) return TCGNN_OK;
@@ -3184,6 +3337,30 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     };
+    // ---- edge values on the LDS-resident flat walk (r04, tcgnn_lds_val.inc; decided above, before the staging pass)
+    if (val_lds) {
+        const tcgnn_plan::CellStream& cs = plan->lds[kLdsValSlot];
+        const size_t image = workspace_bytes_for(plan->Nc, D);
+        _Float16* const vals = reinterpret_cast<_Float16*>(static_cast<char*>(ws) + image);
+        _Float16* const cvals = vals + (size_t)std::max<int64_t>(cs.tiles, 1) * 32;
+        KernelTimer timer(plan, stream, cs.cold_tiles > 0 ? "val_permute_kernel + spmm_lds_val_kernel + spmm_cold_val_kernel (cold remainder)" : "val_permute_kernel + spmm_lds_val_kernel");
+        {
+            static bool attr_set = false;
+            if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)val_permute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kValSpanHalves * 2)); attr_set = true; }
+            hipLaunchKernelGGL(val_permute_kernel, dim3((unsigned)(cs.nwg * kLdsWaves * (kLdsMaxW2 / kValWpb))), dim3(kValThreads), kValSpanHalves * 2, stream, d_val, plan->rowptr, cs.d_order, cs.d_eidx16, cs.d_rbase, hdr,
+                               vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals);
+            HIP_TRY(hipGetLastError());
+        }
+        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist};
+        HIP_TRY(launch_lds_val(va, dpad / 32, stream));
+        if (cs.cold_tiles > 0) {
+            const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad};
+            hipLaunchKernelGGL(spmm_cold_val_kernel, dim3((unsigned)((plan->nw_eff + 3) / 4), (unsigned)((dpad + 63) / 64)), dim3(256), 0, stream, ca);
+            HIP_TRY(hipGetLastError());
+        }
+        timer.stop();
+        return wide_fallback();
+    }
     // ---- edge values on the fused AGNN kernel's XCD-sliced walk (r03).  Where the fused pair's backward pass takes that walk (graphs
     //      without locality of their own, windows alike, an fp16 image of 16 - 64 MB: agnn_walk) the edge-valued SpMM is the same
     //      gather with less to do per tile, so it runs as that kernel with the score half switched off (AgnnArgs::valonly: w = 1,
@@ -3420,8 +3597,9 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
-        (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold);
+        (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold); (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); (void)hipFree(cs.d_eidx16); (void)hipFree(cs.d_cold_eidx16);
     }
+    (void)hipFree(plan->d_xwb_ptr); (void)hipFree(plan->d_xcols); (void)hipFree(plan->d_xmask); (void)hipFree(plan->d_xeidx);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -3728,7 +3906,9 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
         }
         if (all_built && !cold_rows) two_images = false;
     }
-    return image + std::max({agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D), two_images ? image : (size_t)0});
+    // (the edge-valued LDS-resident walk keeps its per-call slot values behind the image, once its stream exists: tcgnn_lds_val.inc)
+    const size_t vals = (round_up(D, 16) % 64 == 0 && round_up(D, 16) <= 2 * kMaxChunkDims) ? val_stream_bytes(plan) : (size_t)0;
+    return image + std::max({agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D), two_images ? image : (size_t)0, vals});
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {

@@ -102,6 +102,20 @@ def node_nll_loss(log_probs, y):
     return -log_probs.gather(1, y.view(-1, 1)).mean()
 
 
+def make_adam(params, lr=0.01):
+    """Adam(lr=0.01, capturable=True) of main_tcgnn.py:143.  On the GPU the FUSED implementation (one kernel per step over all
+    parameters) instead of torch's default foreach form: the same update, but the foreach step is ~30 launches of ~5 us each -
+    0.15 ms of a 2.7 ms Reddit epoch, most of a Citeseer-sized one (profiles/r03/epoch_gcn_timeline.txt).  TCGNN_FUSED_ADAM=0
+    keeps the default form."""
+    params = list(params)
+    if params and params[0].is_cuda and os.environ.get("TCGNN_FUSED_ADAM", "1") != "0":
+        try:
+            return torch.optim.Adam(params, lr=lr, capturable=True, fused=True)
+        except (RuntimeError, TypeError, ValueError):   # (a torch build without the fused kernels)
+            pass
+    return torch.optim.Adam(params, lr=lr, capturable=True)
+
+
 def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, epochs, seed=0, warmup=9, hip_graph=False, tune=True):
     """The timed part of main_tcgnn.py (:141-181) on tensors that already live on the GPU:
     Adam(lr=0.01), nll_loss over all nodes, `warmup` dry epochs then `epochs` timed ones.
@@ -112,7 +126,7 @@ def time_training(model_name, meta, x, y, in_dim, hidden, classes, num_layers, e
     conv_cls = {"gcn": L.GCNConv, "gin": L.GINConv, "agnn": L.AGNNConv}[model_name]
     torch.manual_seed(seed)
     model = Net(conv_cls, in_dim, hidden, classes, num_layers).to(x.device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    optimizer = make_adam(model.parameters())
 
     def train():
         model.train()

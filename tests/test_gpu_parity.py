@@ -624,6 +624,61 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
             assert np.abs(gemm["0"][0].cpu().numpy() - Z.cpu().numpy()).max() <= TIGHT * scale
 
 
+@pytest.mark.parametrize("shape", ["dense", "denser", "multi_edge_columns", "ragged"])
+@pytest.mark.parametrize("D", [64, 128])
+def test_edge_valued_spmm_on_the_lds_resident_walk(dev, T, D, shape, monkeypatch, capfd):
+    """r04: forward_AGNN on the LDS-resident flat walk (tcgnn_lds_val.inc) - the cell stream is cut from a
+    SINGLE-EDGE tile stream, so a K slot carries one edge and the caller's values, brought into stream order per call by
+    val_permute_kernel, sit beside the slots.  Forced (mode 3) on graphs whose cells overflow often (`denser`: the remainder goes
+    through spmm_cold_val_kernel), hardly ever, whose columns hold MANY edges of a window (`multi_edge_columns`: half of all pairs are
+    edges, so a condensed column carries ~8 of a window's rows and is repeated once per edge when the stream is cut) and with N % 16 != 0; against the oracle, the fp64 definition and the per-window gather walk.  The
+    first call builds the stream and still takes a gather walk (its workspace was sized before the stream existed)."""
+    import tcgnn_capi as c
+    if shape == "dense":
+        rp, col = graphs.uniform_graph(4100, 150, seed=21)
+    elif shape == "denser":
+        rp, col = graphs.uniform_graph(3000, 400, seed=23)
+    elif shape == "multi_edge_columns":
+        rp, col = graphs.uniform_graph(1000, 500, seed=25)
+    else:
+        rp, col = graphs.uniform_graph(2061, 120, seed=24)      # N % 16 = 13
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 9)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    att = (rng.standard_normal(nnz) * rng.choice([0.01, 1.0, 30.0])).astype(np.float32)
+    tX, tatt = to_dev(dev, X, att)
+    args = (tX, meta[0], meta[1], tatt.view(1, -1), *meta[2:])
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    monkeypatch.setenv("TCGNN_LDS_FLAT", "1")    # (graphs the oracle can handle have few, long cells: one tile per cell is forced, the rest is the cold remainder)
+    T.clear_plan_cache()
+    try:
+        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+        first = T.forward_AGNN(*args)[0]
+        k_first = T.last_kernel(*meta)
+        Y = T.forward_AGNN(*args)[0]
+        kernel = T.last_kernel(*meta)
+        again = T.forward_AGNN(*args)[0]
+        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+        Y1 = T.forward_AGNN(*args)[0]
+        assert T.last_kernel(*meta) == "spmm_kernel"
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+    err = capfd.readouterr().err
+    ref = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    Y64, absY = O.spmm_f64(X, rp, col, att)
+    unit = float(np.abs(att).max()) <= 8.0
+    assert_parity(first.cpu().numpy(), ref, Y64, absY, "first call (%s)" % k_first, unit)
+    assert_parity(Y1.cpu().numpy(), ref, Y64, absY, "per-window gather walk", unit)
+    # (the first call takes the new walk too when the process already holds a workspace large enough for the slot values)
+    assert "spmm_lds_val_kernel" in kernel, (k_first, kernel, err[-1500:])
+    assert "cold remainder" in kernel, kernel        # (cells of 100+ edges against a cap of 32: most of these graphs is remainder)
+    assert torch.equal(Y, again)                                                     # deterministic
+    assert_parity(Y.cpu().numpy(), ref, Y64, absY, "LDS-resident edge-valued walk", unit)
+    assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+
+
 @pytest.mark.parametrize("D", [16, 41, 64, 96, 128])   # (128: what the backward pass takes on the Reddit shape since r03; 96: the old row layout)
 def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatch):
     """r03: the XCD-sliced walk of the fused kernel (workgroup b gathers only rows of column slice b % 8, so an XCD's L2 holds the
@@ -1315,6 +1370,7 @@ def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary
         assert_parity(got, Yref, Y64, A64, "full-size spmm D=%d, %s (%s)" % (D, tag, T.last_kernel(*meta)))
         if spmm_only:
             return
+        T.forward_AGNN(X, rp, col, att.view(1, -1), bp, e2c, e2r)     # (the first edge-valued call of a plan builds the LDS-resident walk's stream)
         got = T.forward_AGNN(X, rp, col, att.view(1, -1), bp, e2c, e2r)[0][trows].cpu().numpy()
         kernels["%s spmm_val" % tag] = T.last_kernel(*meta)
         assert_parity(got, Yvref, Yv64, Av64, "full-size forward_AGNN D=%d, %s (%s)" % (D, tag, T.last_kernel(*meta)))
