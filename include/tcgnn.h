@@ -175,15 +175,18 @@ int tcgnn_set_spmm_mode(int32_t mode);
 
 /* The range guard (see "Operand range" above), process-wide level (environment TCGNN_RANGE_GUARD sets the initial one):
  *   0  off - every call stays on the MFMA path;
- *   1  (default) the aggregation operators are guarded: tcgnn_spmm / _fused / _gemm and tcgnn_spmm_val, whose error bound is
- *      LINEAR in max|X| - k max 2^-39 - and which ordinary training tensors never reach;
- *   2  also tcgnn_sddmm and the fused AGNN pair, whose bound is QUADRATIC - min(2 D, lost elements) max|X|^2 2^-39: with the
- *      reference's unscaled weights an AGNN epoch's activations (max ~3e4, one element 2^28 below) cross it now and then, and
- *      such a call then costs ~25 ms in the fp32 CSR fallbacks instead of 2 ms.  At levels 0 and 1 those two operators answer to
- *      that bound as documented.  tcgnn_range_mode reports which way the LAST staged call on this
- * workspace went: *wide_x = 1 if its feature matrix took the fp32 fallback as a binary SpMM / SDDMM / fused AGNN operand,
- * *wide_val (optional) = 1 if it did as an edge-valued SpMM.  Reads 32 bytes of the workspace header back: synchronises `stream`
- * (a test / diagnosis aid, like tcgnn_plan_last_kernel - the hot path never reads anything back). */
+ *   1  the aggregation operators are guarded: tcgnn_spmm / _fused / _gemm and tcgnn_spmm_val, whose error bound is LINEAR in
+ *      max|X| - k max 2^-39 - and which ordinary training tensors never reach;
+ *   2  (default since r04) also tcgnn_sddmm and the fused AGNN pair, whose bound is QUADRATIC - min(2 D, lost elements)
+ *      max|X|^2 2^-39: with the reference's unscaled weights an AGNN epoch's activations (max ~3e4, ONE element 2^28 below) cross
+ *      it now and then.  Such a matrix has a handful of "dirty" rows: the MFMA kernels run as usual and one more launch recomputes,
+ *      in fp32 with the reference's operand rounding, exactly the edges that touch them (scores, their share of the aggregate and
+ *      of d_w) - ~0.1 ms when it happens, a launch that returns at once when it does not.  Only a matrix with more than 48 such
+ *      rows goes to the plain CSR fallbacks (slow, correct for any magnitudes).
+ * tcgnn_range_mode reports which way the LAST staged call on this workspace went: *wide_x = 1 if its feature matrix took the fp32
+ * fallback as a binary SpMM / SDDMM / fused AGNN operand, 2 if it stayed on the MFMA path with its dirty rows patched (SDDMM /
+ * fused AGNN), *wide_val (optional) = 1 if it took the fallback as an edge-valued SpMM.  Reads 36 bytes of the workspace header
+ * back: synchronises `stream` (a test / diagnosis aid, like tcgnn_plan_last_kernel - the hot path never reads anything back). */
 int tcgnn_set_range_guard(int32_t level);
 int tcgnn_range_mode(const void* d_workspace, void* stream, int32_t* wide_x, int32_t* wide_val);
 

@@ -186,7 +186,7 @@ def range_mode(device=None):
 
 
 def set_range_guard(level):
-    """Not part of the reference API: the range guard's level - 0 off, 1 the SpMM operators (default), 2 every operator
+    """Not part of the reference API: the range guard's level - 0 off, 1 the SpMM operators only, 2 every operator (default since r04)
     (include/tcgnn.h: tcgnn_set_range_guard)."""
     _c.check(_c.lib.tcgnn_set_range_guard(int(level)), "tcgnn_set_range_guard")
 

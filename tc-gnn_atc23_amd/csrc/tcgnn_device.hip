@@ -205,6 +205,22 @@ __device__ __forceinline__ bool range_is_wide_val(const uint32_t* hdr) {
     const uint32_t n = hdr[6], k = (sa || n >= cap) ? cap : (n ? n : 1u);   // (edge values that lose bits are not counted: the longest row bounds them)
     return (ex - 127) + (ea - 127) >= 28 - ceil_log2_u32(k);
 }
+// ---- SDDMM and the fused AGNN pair at guard level 2 (r04): two ways through a "wide" matrix.  What a training epoch produces is ONE
+// or a few lost elements (tools/probe_training_ranges.py), i.e. a handful of DIRTY ROWS of X - recorded by the conversion pass in
+// header word 8 (count) and words 16 .. 63 (row numbers).  With at most kSparseRows of them the MFMA kernels run as usual and
+// wide_patch_kernel recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch a dirty row (their
+// scores, and what those edges contribute to the aggregate and to d_w): a launch that returns at once when nothing is wide and
+// costs ~0.1 ms when something is.  More dirty rows than that: the MFMA kernels return and the CSR fallbacks do all the work, as
+// before (sparse_ok = 0 keeps that behaviour for the aggregation operators, whose bound is linear and never reached in training).
+static constexpr uint32_t kSparseRows = 48;
+__device__ __forceinline__ bool wide2_sparse(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] <= kSparseRows; }
+__device__ __forceinline__ bool wide2_dense(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] > kSparseRows; }
+// conversion pass: a thread that met an element losing bits records the row (duplicates are possible: the patch de-duplicates)
+__device__ __forceinline__ void note_dirty_row(uint32_t* hdr, uint32_t nt, int64_t row) {
+    if (!hdr || !nt) return;
+    const uint32_t k = atomicAdd(hdr + 8, 1u);
+    if (k < kSparseRows) hdr[16 + k] = (uint32_t)row;
+}
 // conversion pass: this thread's count of elements that lose bits (nonzero, below fp16's normal range once scaled) -> hdr[6]
 __device__ __forceinline__ void count_tiny(uint32_t* cnt, uint32_t mine) {   // mine <= 15; lanes that left the kernel early count as 0
     if (!cnt) return;
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
                                                       int32_t D, int32_t Dpad, int32_t pitch,
                                                       _Float16* __restrict__ X16,
                                                       const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr, int64_t ldx = 0,
-                                                      uint32_t* __restrict__ tiny = nullptr) {
+                                                      uint32_t* __restrict__ tiny = nullptr, uint32_t* __restrict__ dirty_hdr = nullptr) {
     if (ldx == 0) ldx = D;   // row stride of X (and G) in floats: > D when X is a column block of a wider matrix
     const int cpr = Dpad >> 3;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,6 +483,7 @@ __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ 
         }
     }
     *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
+    note_dirty_row(dirty_hdr, nt, row);
     count_tiny(tiny, nt);
 }
 
@@ -1096,7 +1113,7 @@ static constexpr int sddmm_wave_lds(int ks) { return sddmm_nbuf(ks) * (2 * ks * 
 // and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
 template <int KS, int WAVES, bool BLOCKED>
 __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(const SddmmArgs a) {
-    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    if (wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
     constexpr int WAVE_LDS = sddmm_wave_lds(KS);
@@ -1351,7 +1368,7 @@ __global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(co
 // Run-time-K variant for D > 128: window rows are re-read per tile (L1-resident), ordinary loads.
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs a) {
-    if (range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    if (wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -1448,7 +1465,7 @@ static constexpr int agnn_wave_lds(int ks, bool bwd) {
 template <int NT, int WAVES, bool BWD, int MAXW>
 __global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
     const bool valonly = BWD && a.valonly != 0;   // (kernel-uniform)
-    if (valonly ? range_is_wide_val(a.hdr) : range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
+    if (valonly ? range_is_wide_val(a.hdr) : wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work; a few dirty rows: wide_patch_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = (NT + 1) / 2;
     constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
@@ -1930,7 +1947,7 @@ __global__ __launch_bounds__(256) void agnn_slice_sum_kernel(const float* __rest
 // 29 k partials on the Reddit shape, and 256 threads taking one dependent load per step spent 47 us on them (a memory round trip
 // per step) - 2 x 47 us of an AGNN epoch.
 static constexpr int kReduceThreads = 1024;
-__global__ __launch_bounds__(kReduceThreads) void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(kReduceThreads) void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out, const double* __restrict__ extra = nullptr) {
     __shared__ double sh[kReduceThreads];
     double s = 0.0;
     int k = (int)threadIdx.x;
@@ -1945,7 +1962,7 @@ __global__ __launch_bounds__(kReduceThreads) void agnn_reduce_kernel(const doubl
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = (float)sh[0];
+    if (threadIdx.x == 0) out[0] = (float)(sh[0] + (extra ? extra[0] : 0.0));   // (extra: wide_patch_kernel's correction, header words 10-11; zero unless the call was patched)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2055,8 +2072,8 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restric
 __global__ __launch_bounds__(256) void spmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, int use_val_word, const int32_t* __restrict__ rowptr,
                                                                  const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ wscale,
                                                                  const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int32_t N, int32_t D,
-                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe) {
-    if (!(use_val_word ? range_is_wide_val(hdr) : range_is_wide(hdr, 0))) return;
+                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe, int32_t sparse_ok = 0) {
+    if (!(use_val_word ? range_is_wide_val(hdr) : (sparse_ok ? wide2_dense(hdr) : range_is_wide(hdr, 0)))) return;
     const int lane = threadIdx.x & 63;
     const float w = wscale ? wscale[0] : 1.0f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {   // (a small grid: the usual launch returns above)
@@ -2110,7 +2127,7 @@ __global__ __launch_bounds__(256) void spmm_gemm_wide_fallback_kernel(const uint
 __global__ __launch_bounds__(256) void sddmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                   const float* __restrict__ X, float* __restrict__ ef, int32_t N, int32_t D, int32_t row_off,
                                                                   uint32_t* __restrict__ absmax) {
-    if (!range_is_wide(hdr, 0)) return;
+    if (!wide2_dense(hdr)) return;   // (a few dirty rows: wide_patch_kernel behind the MFMA kernel)
     const int lane = threadIdx.x & 63;
     uint32_t m = 0;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {
@@ -2130,7 +2147,7 @@ __global__ __launch_bounds__(256) void sddmm_wide_fallback_kernel(const uint32_t
 // sum_e <rna(dY[row e]), rna(dY[col e])> * (float)col(e), rows and edges in order (deterministic), as doubles for agnn_reduce_kernel
 __global__ __launch_bounds__(64) void agnn_dw_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                    const float* __restrict__ X, double* __restrict__ partial, int32_t N, int32_t D, int32_t row_off, int32_t nw) {
-    if (!range_is_wide(hdr, 0)) return;
+    if (!wide2_dense(hdr)) return;
     const int lane = threadIdx.x & 63;
     double acc = 0.0;
     for (int w = blockIdx.x; w < nw; w += gridDim.x) {
@@ -2149,6 +2166,87 @@ __global__ __launch_bounds__(64) void agnn_dw_wide_fallback_kernel(const uint32_
         }
     }
     if (lane == 0) partial[blockIdx.x] = acc;
+}
+
+// ---- the sparse way through a wide matrix (see wide2_sparse): every edge (r, c) whose row of X or whose column's row of X is dirty
+//      is recomputed in fp32 with the reference's operand rounding.
+//   mode 0 (SDDMM):          ef[e] = <rna(x_r), rna(x_c)>
+//   mode 1 (fused forward):  the same, max |ef| kept up to date, and Y[r] += rna(w ef_new) rna(x_c) - rna(w ef_old) img(x_c): the
+//                            edge's contribution as the reference computes it minus what the MFMA kernel added (img = the fp16 image)
+//   mode 2 (fused backward): X = dY, ef = the saved scores: G[r] += rna(w ef) (rna(x_c) - img(x_c)) and the edge's term of d_w,
+//                            (<rna(x_r), rna(x_c)> - <img(x_r), img(x_c)>) col(e), into one extra double behind the partial sums
+// Workgroups 0 .. kSparseRows - 1 take the edges OF dirty row b (a wavefront's lane = an edge); the others scan the column index
+// for edges INTO a dirty row whose own row is clean.  Atomic adds: the order of the corrections of one row is not fixed - in a path
+// that exists for a handful of rows per call.
+struct PatchArgs {
+    const uint32_t* hdr;
+    const int32_t* rowptr; const int32_t* col; const int32_t* e2r;
+    const float* X; const _Float16* x16; int32_t pitch;
+    float* ef; const float* w; float* Y; uint32_t* efmax; double* dw_extra;
+    int32_t N, Nc, D, row_off, mode; int64_t E;
+};
+__device__ __forceinline__ void patch_edge(const PatchArgs& a, int64_t e, int64_t r, int32_t c, bool c_dirty) {
+    const float* xr = a.X + (r + a.row_off) * a.D;
+    const float* xc = a.X + (int64_t)c * a.D;
+    const _Float16* ir = a.x16 + (r + a.row_off) * a.pitch;
+    const _Float16* ic = a.x16 + (int64_t)c * a.pitch;
+    const float inv = pow2f(-scale_exp_from_bits(a.hdr[0]));
+    float exact = 0.f, dimg = 0.f;
+    for (int d = 0; d < a.D; ++d) { exact += round_rna10(xr[d]) * round_rna10(xc[d]); dimg += ((float)ir[d] * inv) * ((float)ic[d] * inv); }
+    if (a.mode == 0) { a.ef[e] = exact; return; }
+    const float w = a.w[0];
+    if (a.mode == 1) {
+        const float a_old = round_rna10(w * a.ef[e]), a_new = round_rna10(w * exact);
+        a.ef[e] = exact;
+        atomicMax(a.efmax, __float_as_uint(exact) & 0x7fffffffu);
+        for (int d = 0; d < a.D; ++d) atomicAdd(&a.Y[r * a.D + d], a_new * round_rna10(xc[d]) - a_old * ((float)ic[d] * inv));
+        return;
+    }
+    const float att = round_rna10(w * a.ef[e]);
+    if (c_dirty)
+        for (int d = 0; d < a.D; ++d) atomicAdd(&a.Y[r * a.D + d], att * (round_rna10(xc[d]) - (float)ic[d] * inv));
+    atomicAdd(a.dw_extra, ((double)exact - (double)dimg) * (double)(float)c);
+}
+__global__ __launch_bounds__(256) void wide_patch_kernel(const PatchArgs a) {
+    if (!wide2_sparse(a.hdr)) return;
+    __shared__ int32_t dirty[kSparseRows];
+    __shared__ int32_t ndirty;
+    if (threadIdx.x == 0) {   // the list without duplicates, sorted (48 entries: insertion sort)
+        const int n = (int)min(a.hdr[8], kSparseRows);
+        int m = 0;
+        for (int k = 0; k < n; ++k) {
+            const int32_t v = (int32_t)a.hdr[16 + k];
+            int j = 0;
+            while (j < m && dirty[j] < v) ++j;
+            if (j < m && dirty[j] == v) continue;
+            for (int q = m; q > j; --q) dirty[q] = dirty[q - 1];
+            dirty[j] = v; ++m;
+        }
+        ndirty = m;
+    }
+    __syncthreads();
+    const int nd = ndirty;
+    auto is_dirty = [&](int32_t x) { int lo = 0, hi = nd; while (lo < hi) { const int mid = (lo + hi) >> 1; if (dirty[mid] < x) lo = mid + 1; else hi = mid; } return lo < nd && dirty[lo] == x; };
+    if (blockIdx.x < kSparseRows) {
+        if ((int)blockIdx.x >= nd) return;
+        const int64_t r = (int64_t)dirty[blockIdx.x] - a.row_off;       // the row of A this row of X belongs to
+        if (r < 0 || r >= a.N) return;
+        for (int64_t e = a.rowptr[r] + threadIdx.x; e < a.rowptr[r + 1]; e += blockDim.x) patch_edge(a, e, r, a.col[e], is_dirty(a.col[e]));
+        return;
+    }
+    const int64_t first = (int64_t)(blockIdx.x - kSparseRows) * blockDim.x + threadIdx.x, step = (int64_t)(gridDim.x - kSparseRows) * blockDim.x;
+    const int32_t lo_id = nd ? dirty[0] : 0, hi_id = nd ? dirty[nd - 1] : -1;
+    for (int64_t e = first; e < a.E; e += step) {
+        const int32_t c = a.col[e];
+        if (c < lo_id || c > hi_id || !is_dirty(c)) continue;
+        const int64_t r = a.e2r[e];
+        if (r < 0 || r >= a.N || is_dirty((int32_t)(r + a.row_off))) continue;      // (its own row is dirty: the row's workgroup patches it)
+        patch_edge(a, e, r, c, true);
+    }
+}
+static hipError_t launch_wide_patch(const PatchArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(wide_patch_kernel, dim3(kSparseRows + 1024), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2341,7 +2439,7 @@ static size_t agnn_slice_bytes(const tcgnn_plan* plan, int32_t D) {
 // ---- range guard parameters (range_is_wide): cap = how many lost-precision terms one result can collect at most - the longest row
 // of the graph (SpMM) or 2 D (SDDMM / fused AGNN) - and the power of max|X| in the error bound.  cap 0 = guard off
 // (tcgnn_set_range_guard(0), TCGNN_RANGE_GUARD=0).
-static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 1; }();
+static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 2; }();   // (r04: every operator - the usual wide input costs one patch launch)
 struct Guard { uint32_t cap, pow; };
 static Guard guard_spmm(const tcgnn_plan* p) { return {g_range_guard ? (uint32_t)std::max(p->max_degree, 1) : 0u, 1u}; }
 // (level 1, the default: the aggregation operators - binary and edge-valued SpMM, the fused dense update - whose bound is linear in
@@ -2368,7 +2466,7 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     const int dpad = round_up(D, 16);
     const int pitch = x16_pitch(dpad);
     if (hdr_from) { HIP_TRY(hipMemcpyAsync(hdr, hdr_from, 32, hipMemcpyDeviceToDevice, stream)); block_of_wider = true; }
-    else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 32, stream));
+    else if (!block_of_wider) HIP_TRY(hipMemsetAsync(hdr, 0, 64, stream));   // (words 0 .. 7: range words; 8: dirty-row count)
     const int64_t nx = block_of_wider ? 0 : (int64_t)plan->Nc * D;
     if (nx > 0) {
         const int grid = absmax_grid(nx);
@@ -2392,8 +2490,11 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
             hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
                                d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
         else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
-    } else if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny);
-    else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny);
+    } else {
+        uint32_t* const dirty = (tiny && gx.pow == 2u && gx.cap) ? hdr : nullptr;   // (SDDMM / fused AGNN at guard level 2: dirty rows for wide_patch_kernel)
+        if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny, dirty);
+        else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny, dirty);
+    }
     HIP_TRY(hipGetLastError());
     *hdr_out = hdr; *x16_out = x16; *dpad_out = dpad; *pitch_out = pitch;
     return TCGNN_OK;
@@ -3558,16 +3659,22 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         }
         HIP_TRY(e);
     }
-    if (g_range_guard >= 2) {   // the range guard's fallbacks (each returns at once unless the staged matrix is "wide"): the same two products in fp32
+    // (the d_w correction of the patch: a double in header words 10-11, zeroed with the header by the staging pass)
+    double* const dw_extra = reinterpret_cast<double*>(const_cast<uint32_t*>(hdr) + 10);
+    if (g_range_guard >= 2) {
+        // a few dirty rows (what training produces): the MFMA kernel above ran, the edges that touch them are recomputed here
+        const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, d_w, d_Y, d_absmax, dw_extra, plan->N, plan->Nc, D, plan->row_off, bwd ? 2 : 1, plan->E};
+        HIP_TRY(launch_wide_patch(pa, stream));
+        // many: the range guard's fallbacks (each returns at once unless the staged matrix is "wide" AND holds more dirty rows than the patch takes)
         const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096);
         if (!bwd) hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_ef, plan->N, D, plan->row_off, d_absmax);
         hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, 0, plan->rowptr, plan->col, (const float*)d_ef, d_w, d_X, (const float*)nullptr, d_Y,
-                           plan->N, D, (int64_t)D, (int64_t)D, 0, 0);
+                           plan->N, D, (int64_t)D, (int64_t)D, 0, 0, 1);
         if (bwd) hipLaunchKernelGGL(agnn_dw_wide_fallback_kernel, dim3((unsigned)nwg), dim3(64), 0, stream, hdr, plan->rowptr, plan->col, d_X, partial, plan->N, D, plan->row_off, plan->nw_eff);
         HIP_TRY(hipGetLastError());
     }
     if (bwd) {
-        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw);
+        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw, g_range_guard >= 2 ? dw_extra : (const double*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return TCGNN_OK;
@@ -3832,7 +3939,7 @@ int tcgnn_set_range_guard(int32_t level) {
 
 int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, int32_t* wide_val) {
     if (!d_workspace || !wide_x) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_range_mode: null argument");
-    uint32_t h[8];
+    uint32_t h[9];
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     HIP_TRY(hipMemcpyAsync(h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -3845,6 +3952,7 @@ int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, i
     int ex = 0, ea = 0;
     const bool sx = spread(0, ex), sa = spread(1, ea);
     *wide_x = (sx && h[4] != 0u && h[6] != 0u && (int)h[7] * (ex - 127) >= 29 - clog2(std::min(h[4], h[6]))) ? 1 : 0;
+    if (*wide_x && h[7] == 2u && h[8] <= kSparseRows) *wide_x = 2;   // (SDDMM / fused AGNN with a few dirty rows: the MFMA kernel + wide_patch_kernel)
     if (wide_val) {
         const uint32_t k = (sa || h[6] >= h[5]) ? h[5] : std::max(h[6], 1u);
         *wide_val = ((sx || sa) && h[5] != 0u && h[0] != 0u && h[1] != 0u && (ex - 127) + (ea - 127) >= 28 - clog2(k)) ? 1 : 0;
@@ -4024,8 +4132,12 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     HIP_TRY(e);
     timer.stop();
     // (the range guard's fallback: returns at once unless X is "wide")
-    if (g_range_guard >= 2) hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096)), dim3(256), 0, stream, hdr, plan->rowptr, plan->col,
-                                                d_X, d_ef, plan->N, D, plan->row_off, (uint32_t*)nullptr);
+    if (g_range_guard >= 2) {   // a few dirty rows: the patch behind the MFMA kernel; many: the CSR fallback (each returns at once otherwise)
+        const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, nullptr, nullptr, nullptr, nullptr, plan->N, plan->Nc, D, plan->row_off, 0, plan->E};
+        HIP_TRY(launch_wide_patch(pa, stream));
+        hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096)), dim3(256), 0, stream, hdr, plan->rowptr, plan->col,
+                           d_X, d_ef, plan->N, D, plan->row_off, (uint32_t*)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;
 }

@@ -1085,8 +1085,130 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
     try:
         _wide_range_body(dev, T)
     finally:
-        T.set_range_guard(1)      # the default level, whatever happened
+        T.set_range_guard(2)      # the default level (r04), whatever happened
         T.clear_plan_cache()
+
+
+@pytest.mark.parametrize("specks", [1, 5, 12])
+def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks):
+    """r04: the default guard level covers SDDMM and the fused AGNN pair.  What training produces is a matrix
+    of 1e4-sized activations with ONE element 2^28 below the maximum (tools/probe_training_ranges.py): the quadratic bound makes it
+    "wide", and until r04 such a call either kept the documented bound (default) or spent ~25 ms in the CSR fallbacks (level 2).
+    Now the MFMA kernels run and wide_patch_kernel recomputes the edges that touch the few dirty rows in fp32: range_mode says 2,
+    the scores of exactly those edges come out to accumulation accuracy of their own terms (the fp16 image alone misses by orders
+    of magnitude there), everything else is untouched, aggregate and d_w follow."""
+    assert T.range_mode is not None
+    T.set_range_guard(2)
+    rp, col = graphs.uniform_graph(4000, 100, seed=5)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    n, D = len(rp) - 1, 64
+    rng = np.random.default_rng(100 + specks)
+    X = (rng.standard_normal((n, D)) * 1e4).astype(np.float32)
+    X[np.abs(X) < 1.0] = 1.0
+    rows = rng.choice(n, size=specks, replace=False)
+    for r in rows:
+        X[r, rng.integers(0, D, size=3)] = 3e-5 * (1.0 + rng.random(3))       # ~2^30 below the maximum: fp16 subnormals lose most of their bits
+    tX = torch.from_numpy(X).to(dev)
+    ef = T.forward_ef(tX, *meta)[0].cpu().numpy()
+    assert T.range_mode()[0] == 2
+    refe = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, ae64 = O.sddmm_f64(X, rp, col)
+    assert (np.abs(ef - refe) / (ae64 + 1e-30)).max() <= 4 * TIGHT
+    # sensitivity: the lost elements' own products are visible at this accuracy (each is ~3e-5 x 1e4 = 0.3 against sums of ~1e9 x 4e-6)
+    erow = np.repeat(np.arange(n), np.diff(rp))
+    touched = np.isin(erow, rows) | np.isin(col, rows)
+    assert touched.sum() >= specks * 100
+    w = np.float32(0.75)
+    tw = torch.tensor([w], device=dev)
+    Yf, ef_f, efm = T.agnn_fused_forward(tX, meta[0], meta[1], tw, *meta[2:])
+    assert T.range_mode()[0] == 2
+    ef_fh = ef_f.cpu().numpy()
+    assert (np.abs(ef_fh - refe) / (ae64 + 1e-30)).max() <= 4 * TIGHT
+    assert int(efm.item()) == int(np.abs(ef_fh).max().view(np.int32))
+    att_ref = (w * ef_fh).astype(np.float32)
+    refY = O.spmm_val(X, rp, col, att_ref, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, aY = O.spmm_f64(X, rp, col, att_ref)
+    assert (np.abs(Yf.cpu().numpy() - refY) / (aY + 1e-30)).max() <= 256 * TIGHT
+    dY = (rng.standard_normal((n, D)) * 1e4).astype(np.float32)
+    dY[np.abs(dY) < 1.0] = 1.0
+    for r in rows:
+        dY[r, rng.integers(0, D, size=2)] = 3e-5
+    tdY = torch.from_numpy(dY).to(dev)
+    G, dw = T.agnn_fused_backward(tdY, meta[0], meta[1], tw, ef_f, efm, *meta[2:])
+    assert T.range_mode()[0] == 2
+    refG = O.spmm_val(dY, rp, col, att_ref, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, aG = O.spmm_f64(dY, rp, col, att_ref)
+    assert (np.abs(G.cpu().numpy() - refG) / (aG + 1e-30)).max() <= 256 * TIGHT
+    d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, ad = O.sddmm_f64(dY, rp, col)
+    want_dw = float((d_att.astype(np.float64) * col.astype(np.float64)).sum())
+    assert abs(float(dw) - want_dw) <= 1e-5 * (float((ad * col).sum()) + 1.0), (float(dw), want_dw)
+    # with the guard at level 1 the same call stays on the MFMA path alone and misses the touched edges by far more than that
+    T.set_range_guard(1)
+    try:
+        ef1 = T.forward_ef(tX, *meta)[0].cpu().numpy()
+        assert T.range_mode()[0] == 0
+        # (the lost elements' own products - 3e-5 x 1e4 against sums of |terms| ~ 6e9 - are far below accumulation noise here: what
+        #  makes the matrix "wide" is the worst case over all cancellations, which the patch removes by construction)
+        assert not np.array_equal(ef1[touched], ef[touched])                # the patch recomputed the touched edges (another summation order) ...
+        assert np.array_equal(ef1[~touched], ef[~touched])                  # ... and nothing else
+    finally:
+        T.set_range_guard(2)
+        T.clear_plan_cache()
+
+
+def test_agnn_training_with_the_reference_recipe_stays_inside_the_bar(dev, T):
+    """20 AGNN epochs with the reference's UNSCALED randn feature weights (gnn_conv.py:195 style activations of 1e4 and more) on a
+    graph the oracle can follow: at the default guard level every fused forward call's scores and aggregate stay within
+    1e-3 max(1, |ref|) of an fp64 evaluation of the definition on the TF32-rounded operands, whichever way the guard sent the call."""
+    import tcgnn_harness as H
+    import tcgnn_layers as L
+    rp, col = graphs.uniform_graph(3000, 30, seed=8)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    n = len(rp) - 1
+    erow = torch.from_numpy(np.repeat(np.arange(n), np.diff(rp))).to(dev)
+    tcol = meta[1].long()
+    seen = {"calls": 0, "wide": 0, "worst_ef": 0.0, "worst_Y": 0.0}
+    real = T.agnn_fused_forward
+
+    def rna10(t):
+        u = t.contiguous().view(torch.int32)
+        return ((u + 0x1000) & ~0x1fff).view(torch.float32)
+
+    def checked(X, rowptr, cols, w, *rest):
+        Y, ef, efm = real(X, rowptr, cols, w, *rest)
+        seen["calls"] += 1
+        seen["wide"] += int(T.range_mode()[0] != 0)
+        xr = rna10(X).double()
+        # the bar, plus what fp32 accumulation in ANY order (the reference's tensor-core order included) leaves on a cancelling sum:
+        # noise relative to the sum of |terms| (assert_parity's two bounds in one)
+        prod = xr[erow] * xr[tcol]
+        ref_ef, abs_ef = prod.sum(1), prod.abs().sum(1)
+        err = ((ef.double() - ref_ef).abs() / (TOL * ref_ef.abs().clamp(min=1.0) + 16 * TIGHT * abs_ef)).max().item()
+        seen["worst_ef"] = max(seen["worst_ef"], err)
+        att = rna10((w.reshape(-1)[0] * ef)).double()
+        terms = att[:, None] * xr[tcol]
+        ref_Y = torch.zeros(n, X.shape[1], dtype=torch.float64, device=dev).index_add_(0, erow, terms)
+        abs_Y = torch.zeros(n, X.shape[1], dtype=torch.float64, device=dev).index_add_(0, erow, terms.abs())
+        errY = ((Y.double() - ref_Y).abs() / (TOL * ref_Y.abs().clamp(min=1.0) + 16 * TIGHT * abs_Y)).max().item()
+        seen["worst_Y"] = max(seen["worst_Y"], errY)
+        return Y, ef, efm
+
+    T.agnn_fused_forward = checked
+    try:
+        torch.manual_seed(0)
+        g = torch.Generator(device=dev).manual_seed(0)
+        feats = torch.randn(n, 96, device=dev, generator=g)
+        labels = torch.ones(n, dtype=torch.long, device=dev)
+        model = H.Net(L.AGNNConv, 96, 64, 8, 2).to(dev)
+        for conv in (model.conv1, model.conv2):
+            conv.weights.data.normal_()                  # the reference's GCN / GIN recipe, unscaled (AGNNConv's own reset scales by 1 / sqrt(out))
+        opt = H.make_adam(model.parameters())
+        for _ in range(20):
+            model.train(); opt.zero_grad()
+            loss = H.node_nll_loss(model(feats, meta), labels)
+            loss.backward(); opt.step()
+    finally:
+        T.agnn_fused_forward = real
+        T.clear_plan_cache()
+    assert seen["calls"] >= 40
+    assert seen["worst_ef"] <= 1.0 and seen["worst_Y"] <= 1.0, seen       # (errors in units of the combined bound)
 
 
 def _wide_range_body(dev, T):
