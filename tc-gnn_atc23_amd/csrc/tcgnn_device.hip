@@ -210,8 +210,9 @@ __device__ __forceinline__ bool range_is_wide_val(const uint32_t* hdr) {
 // header word 8 (count) and words 16 .. 63 (row numbers).  With at most kSparseRows of them the MFMA kernels run as usual and
 // wide_patch_kernel recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch a dirty row (their
 // scores, and what those edges contribute to the aggregate and to d_w): a launch that returns at once when nothing is wide and
-// costs ~0.1 ms when something is.  More dirty rows than that: the MFMA kernels return and the CSR fallbacks do all the work, as
-// before (sparse_ok = 0 keeps that behaviour for the aggregation operators, whose bound is linear and never reached in training).
+// costs ~0.1 ms when something is.  More dirty rows than that: the MFMA kernels return and the same launch does all the work in
+// plain fp32 (wide_dense_body).  The aggregation operators, whose bound is linear and never reached in training, keep their own
+// fallback kernels (spmm_wide_fallback_kernel, the fp32-MFMA walk).
 static constexpr uint32_t kSparseRows = 48;
 __device__ __forceinline__ bool wide2_sparse(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] <= kSparseRows; }
 __device__ __forceinline__ bool wide2_dense(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] > kSparseRows; }
@@ -2072,8 +2073,8 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restric
 __global__ __launch_bounds__(256) void spmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, int use_val_word, const int32_t* __restrict__ rowptr,
                                                                  const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ wscale,
                                                                  const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int32_t N, int32_t D,
-                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe, int32_t sparse_ok = 0) {
-    if (!(use_val_word ? range_is_wide_val(hdr) : (sparse_ok ? wide2_dense(hdr) : range_is_wide(hdr, 0)))) return;
+                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe) {
+    if (!(use_val_word ? range_is_wide_val(hdr) : range_is_wide(hdr, 0))) return;
     const int lane = threadIdx.x & 63;
     const float w = wscale ? wscale[0] : 1.0f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {   // (a small grid: the usual launch returns above)
@@ -2123,51 +2124,6 @@ __global__ __launch_bounds__(256) void spmm_gemm_wide_fallback_kernel(const uint
     }
     }
 }
-// ef[e] = <rna(X[row e]), rna(X[col e])>; absmax (optional): bits of max |ef| (the fused AGNN forward records it for its backward)
-__global__ __launch_bounds__(256) void sddmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                                  const float* __restrict__ X, float* __restrict__ ef, int32_t N, int32_t D, int32_t row_off,
-                                                                  uint32_t* __restrict__ absmax) {
-    if (!wide2_dense(hdr)) return;   // (a few dirty rows: wide_patch_kernel behind the MFMA kernel)
-    const int lane = threadIdx.x & 63;
-    uint32_t m = 0;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {
-    const float* xr = X + (row + row_off) * D;
-    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
-        const float* xc = X + (int64_t)col[e] * D;
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) { ef[e] = s; m = max(m, __float_as_uint(s) & 0x7fffffffu); }
-    }
-    }
-    if (absmax && lane == 0 && m) atomicMax(absmax, m);
-}
-// the fused AGNN backward's attention-weight gradient: partial[k] = sum over windows k, k + gridDim.x, ... of
-// sum_e <rna(dY[row e]), rna(dY[col e])> * (float)col(e), rows and edges in order (deterministic), as doubles for agnn_reduce_kernel
-__global__ __launch_bounds__(64) void agnn_dw_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                                   const float* __restrict__ X, double* __restrict__ partial, int32_t N, int32_t D, int32_t row_off, int32_t nw) {
-    if (!wide2_dense(hdr)) return;
-    const int lane = threadIdx.x & 63;
-    double acc = 0.0;
-    for (int w = blockIdx.x; w < nw; w += gridDim.x) {
-        for (int r = 0; r < kWinRows; ++r) {
-            const int64_t row = (int64_t)w * kWinRows + r;
-            if (row >= N) break;
-            const float* xr = X + (row + row_off) * D;
-            for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
-                const float* xc = X + (int64_t)col[e] * D;
-                float s = 0.f;
-                for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                acc += (double)s * (double)(float)col[e];
-            }
-        }
-    }
-    if (lane == 0) partial[blockIdx.x] = acc;
-}
-
 // ---- the sparse way through a wide matrix (see wide2_sparse): every edge (r, c) whose row of X or whose column's row of X is dirty
 //      is recomputed in fp32 with the reference's operand rounding.
 //   mode 0 (SDDMM):          ef[e] = <rna(x_r), rna(x_c)>
@@ -2207,8 +2163,49 @@ __device__ __forceinline__ void patch_edge(const PatchArgs& a, int64_t e, int64_
         for (int d = 0; d < a.D; ++d) atomicAdd(&a.Y[r * a.D + d], att * (round_rna10(xc[d]) - (float)ic[d] * inv));
     atomicAdd(a.dw_extra, ((double)exact - (double)dimg) * (double)(float)c);
 }
-__global__ __launch_bounds__(256) void wide_patch_kernel(const PatchArgs a) {
-    if (!wide2_sparse(a.hdr)) return;
+// the dense way through a wide matrix, inside the same launch (more than kSparseRows dirty rows: the MFMA kernel returned at once):
+// plain fp32 in CSR order with the reference's operand rounding (as spmm_wide_fallback_kernel), a wavefront per row - every row's
+// scores, then its aggregate from them, then (backward) its share of d_w into this workgroup's partial sum.
+__device__ __forceinline__ void wide_dense_body(const PatchArgs& a, double* partial, int32_t npartial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = a.mode == 2 ? (int)min((uint32_t)gridDim.x, (uint32_t)npartial) : (int)gridDim.x;
+    __shared__ double wsum[4];
+    double acc = 0.0;
+    uint32_t m = 0u;
+    const float w = a.w ? a.w[0] : 1.0f;
+    if ((int)blockIdx.x < nb)
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.N; row += (int64_t)nb * 4) {
+        const float* xr = a.X + (row + a.row_off) * a.D;
+        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+        if (a.mode != 2 || a.dw_extra)
+            for (int64_t e = e0; e < e1; ++e) {
+                const float* xc = a.X + (int64_t)a.col[e] * a.D;
+                float s = 0.f;
+                for (int d = lane; d < a.D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (a.mode == 2) acc += (double)s * (double)(float)a.col[e];
+                else if (lane == 0) { a.ef[e] = s; m = max(m, __float_as_uint(s) & 0x7fffffffu); }
+            }
+        if (a.mode == 0) continue;
+        __threadfence_block();            // (mode 1: this wavefront reads back the scores its lane 0 has just written)
+        for (int d = lane; d < a.D; d += 64) {
+            float s = 0.f;
+            for (int64_t e = e0; e < e1; ++e) s += round_rna10(w * a.ef[e]) * round_rna10(a.X[(int64_t)a.col[e] * a.D + d]);
+            a.Y[row * a.D + d] = s;
+        }
+    }
+    if (a.mode == 1 && a.efmax && lane == 0 && m) atomicMax(a.efmax, m);
+    if (a.mode == 2) {
+        if (lane == 0) wsum[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = (int)blockIdx.x; k < npartial; k += (int)gridDim.x) partial[k] = (k == (int)blockIdx.x && (int)blockIdx.x < nb) ? (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]) : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void wide_patch_kernel(const PatchArgs a, double* partial, int32_t npartial) {
+    if (!range_is_wide(a.hdr, 0)) return;
+    if (a.hdr[8] > kSparseRows) { wide_dense_body(a, partial, npartial); return; }
     __shared__ int32_t dirty[kSparseRows];
     __shared__ int32_t ndirty;
     if (threadIdx.x == 0) {   // the list without duplicates, sorted (48 entries: insertion sort)
@@ -2244,8 +2241,8 @@ __global__ __launch_bounds__(256) void wide_patch_kernel(const PatchArgs a) {
         patch_edge(a, e, r, c, true);
     }
 }
-static hipError_t launch_wide_patch(const PatchArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(wide_patch_kernel, dim3(kSparseRows + 1024), dim3(256), 0, stream, a);
+static hipError_t launch_wide_patch(const PatchArgs& a, hipStream_t stream, double* partial = nullptr, int32_t npartial = 0) {
+    hipLaunchKernelGGL(wide_patch_kernel, dim3(kSparseRows + 1024), dim3(256), 0, stream, a, partial, npartial);
     return hipGetLastError();
 }
 
@@ -3664,14 +3661,9 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     if (g_range_guard >= 2) {
         // a few dirty rows (what training produces): the MFMA kernel above ran, the edges that touch them are recomputed here
         const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, d_w, d_Y, d_absmax, dw_extra, plan->N, plan->Nc, D, plan->row_off, bwd ? 2 : 1, plan->E};
-        HIP_TRY(launch_wide_patch(pa, stream));
-        // many: the range guard's fallbacks (each returns at once unless the staged matrix is "wide" AND holds more dirty rows than the patch takes)
-        const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096);
-        if (!bwd) hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_ef, plan->N, D, plan->row_off, d_absmax);
-        hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, 0, plan->rowptr, plan->col, (const float*)d_ef, d_w, d_X, (const float*)nullptr, d_Y,
-                           plan->N, D, (int64_t)D, (int64_t)D, 0, 0, 1);
-        if (bwd) hipLaunchKernelGGL(agnn_dw_wide_fallback_kernel, dim3((unsigned)nwg), dim3(64), 0, stream, hdr, plan->rowptr, plan->col, d_X, partial, plan->N, D, plan->row_off, plan->nw_eff);
-        HIP_TRY(hipGetLastError());
+        // (many: the same launch does all the work in plain fp32 - wide_dense_body; one launch per call either way, returning at once
+        //  unless the staged matrix is "wide")
+        HIP_TRY(launch_wide_patch(pa, stream, partial, nwg));
     }
     if (bwd) {
         hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw, g_range_guard >= 2 ? dw_extra : (const double*)nullptr);
@@ -4135,8 +4127,6 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     if (g_range_guard >= 2) {   // a few dirty rows: the patch behind the MFMA kernel; many: the CSR fallback (each returns at once otherwise)
         const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, nullptr, nullptr, nullptr, nullptr, plan->N, plan->Nc, D, plan->row_off, 0, plan->E};
         HIP_TRY(launch_wide_patch(pa, stream));
-        hipLaunchKernelGGL(sddmm_wide_fallback_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096)), dim3(256), 0, stream, hdr, plan->rowptr, plan->col,
-                           d_X, d_ef, plan->N, D, plan->row_off, (uint32_t*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     return TCGNN_OK;

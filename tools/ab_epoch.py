@@ -22,6 +22,8 @@ res = {}
 for rnd in range(rounds):
     for val in ("0", "1"):
         os.environ[var] = val
+        if var == "RANGE_GUARD":          # (process-wide level, not an environment switch after start-up: 0 -> level 1, 1 -> level 2)
+            TCGNN.set_range_guard(1 + int(val))
         for model in ("gcn", "agnn"):
             r = H.time_training(model, meta, feats, labels, in_dim, hidden, classes, 2, 10, seed=0)
             res.setdefault((model, val), []).append(r["train_ms"])
