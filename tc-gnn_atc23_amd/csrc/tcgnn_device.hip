@@ -26,6 +26,18 @@
 //     (4) reads B fragments with ds_read_b64_tr_b16 (hardware transpose: K runs over gathered
 //         rows, which are the LDS rows) and issues one v_mfma_f32_16x16x32_f16 per 16 columns;
 //   partial accumulators of the wavefronts are summed through LDS in a fixed order.
+//
+// File map (r04: one translation unit - the kernels are templates their launchers instantiate - cut by operator):
+//   tcgnn_device.hip          plan struct, range-guard helpers, launch tables, run_spmm / run_agnn, the C ABI
+//   tcgnn_pack_stage.inc      plan-time kernels (pack, locality, longest row) and the staging pass (abs-max, fp16 images)
+//   tcgnn_gather_spmm.inc     TileWalker, spmm_kernel, spmm_blocked_kernel            (+ generated tcgnn_lds_blocks.inc)
+//   tcgnn_lds_spmm.inc        LDS-resident SpMM, ordinary cell stream; cell-stream build kernels
+//   tcgnn_lds_flat.inc        LDS-resident SpMM, flat cell stream (the headline kernel)
+//   tcgnn_lds_val.inc         LDS-resident edge-valued SpMM (single-edge stream, per-call slot values)
+//   tcgnn_sddmm.inc           sddmm_kernel, sddmm_wide_kernel
+//   tcgnn_agnn.inc            agnn_kernel (fused pair, forward / backward), slice sum, d_w reduction
+//   tcgnn_small_fallback.inc  spmm_small_kernel, CSR kernels of non-canonical plans, the range guard's fallbacks, wide_patch_kernel
+//   tcgnn_lds_plan.inc        host side of the LDS-resident walks: time models, placement, build_lds_cells, build_val_stream
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -297,1954 +309,20 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
     return __builtin_bit_cast(half4, v);
 }
 
-// ------------------------------------------------------------------------------------------
-// pack: legacy (nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow) -> tile stream
-// ------------------------------------------------------------------------------------------
-// Locality of the numbering: how many condensed columns lie within `reach` rows of their own window.  A uniform random graph gives
-// 2 reach / num_cols (1/8 at reach = num_cols / 16), a graph whose communities are numbered consecutively nearly all of them.
-// Decides between the per-window walk in XCD-contiguous order (co-resident workgroups share their gathered rows in L2) and the
-// range-blocked walk (which picks its windows strided over the whole graph).
-// longest row of the CSR (grid-stride; one atomic per workgroup)
-__global__ __launch_bounds__(256) void max_degree_kernel(const int32_t* __restrict__ rowptr, int32_t N, uint32_t* out) {
-    uint32_t m = 0;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t d = rowptr[r + 1] - rowptr[r];
-        m = max(m, d > 0 ? (uint32_t)d : 0u);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    __shared__ uint32_t wm[4];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) { m = max(max(wm[0], wm[1]), max(wm[2], wm[3])); if (m) atomicMax(out, m); }
-}
+#include "tcgnn_pack_stage.inc"
 
-__global__ __launch_bounds__(256) void locality_kernel(const int64_t* __restrict__ wb_ptr, const int32_t* __restrict__ cols, int32_t nw, int32_t Nc,
-                                                       int32_t row_off, int32_t reach, unsigned long long* __restrict__ out) {
-    const int w = blockIdx.x;
-    if (w >= nw) return;
-    const int64_t tb = wb_ptr[w] * kWbCols, n = (wb_ptr[w + 1] - wb_ptr[w]) * kWbCols;
-    const int64_t centre = (int64_t)row_off + (int64_t)w * kWinRows + kWinRows / 2;
-    unsigned near = 0, all = 0;
-    for (int64_t q = threadIdx.x; q < n; q += blockDim.x) {
-        const int32_t c = cols[tb + q];
-        if (c >= Nc) continue;
-        ++all;
-        const int64_t d = (int64_t)c - centre;
-        near += (d < 0 ? -d : d) <= reach;
-    }
-    for (int o = 32; o > 0; o >>= 1) { near += __shfl_down(near, o); all += __shfl_down(all, o); }
-    if ((threadIdx.x & 63) == 0 && all) { atomicAdd(&out[0], (unsigned long long)near); atomicAdd(&out[1], (unsigned long long)all); }
-}
+#include "tcgnn_gather_spmm.inc"
 
-__global__ __launch_bounds__(256) void pack_kernel(const int32_t* __restrict__ rowptr,
-                                                   const int32_t* __restrict__ col,
-                                                   const int32_t* __restrict__ e2c,
-                                                   const int32_t* __restrict__ e2r,
-                                                   const int64_t* __restrict__ wb_ptr, int32_t N,
-                                                   int32_t Nc, int32_t* cols, uint32_t* mask,
-                                                   int32_t* ebase, int32_t* flags) {
-    const int w = blockIdx.x;
-    const int64_t n0 = (int64_t)w * kWinRows;
-    const int64_t n1 = n0 + kWinRows < N ? n0 + kWinRows : N;
-    const int64_t base = wb_ptr[w];
-    const int64_t nwb = wb_ptr[w + 1] - base;
-    for (int64_t k = threadIdx.x; k < nwb * kWbCols; k += blockDim.x) cols[base * kWbCols + k] = Nc; // zero sentinel row
-    for (int64_t k = threadIdx.x; k < nwb * kWinRows; k += blockDim.x) {
-        mask[base * kWinRows + k] = 0u;
-        ebase[base * kWinRows + k] = 0;
-    }
-    __syncthreads();
-    if (n0 >= N) return;
-    const int64_t e0 = rowptr[n0], e1 = rowptr[n1];
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const int c = e2c[e];
-        const int r = e2r[e] - (int)n0;
-        const int v = col[e];
-        if (c < 0 || (int64_t)c >= nwb * kWbCols || r < 0 || r >= kWinRows || v < 0 || v >= Nc) {
-            flags[0] = 1;
-            continue;
-        }
-        const int64_t tile = base + (c >> 5);
-        cols[tile * kWbCols + (c & 31)] = v; // duplicates of a column write the same id
-        atomicOr(&mask[tile * kWinRows + r], 1u << (c & 31));
-        bool first_in_tile_row = true;
-        if (e > e0 && e2r[e - 1] - (int)n0 == r) {
-            const int cp = e2c[e - 1];
-            if (cp >= c) flags[1] = 1; // row not strictly increasing: edge-offset table unusable
-            first_in_tile_row = (cp >> 5) != (c >> 5);
-        }
-        if (first_in_tile_row) ebase[tile * kWinRows + r] = (int32_t)e;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// staging: absmax + fp32 -> scaled fp16 copy with a zero sentinel row
-// ------------------------------------------------------------------------------------------
-// (out_lo: where the smallest nonzero magnitude is recorded for the range guard, nullptr: not wanted - images a caller stages
-//  itself, tcgnn_stage_absmax, carry no such word and are never "wide")
-// Both absmax kernels: kAbsmaxThreads threads per workgroup, four independent 16-byte loads in flight per thread (r03: one load per
-// trip of a grid-stride loop left 8 KB in flight per CU - 25 us for the 60 MB of a Reddit-shaped X, 2.4 TB/s), one atomic per
-// workgroup and word.
-constexpr int kAbsmaxThreads = 1024;
-// one workgroup per CU at most, and none without sixteen 16-byte loads per thread to do
-static inline int absmax_grid(int64_t n) { return (int)std::min<int64_t>(256, n / ((int64_t)kAbsmaxThreads * 64) + 1); }
-template <bool GATED>
-__device__ __forceinline__ void absmax_body(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo,
-                                            uint32_t guard_cap, uint32_t guard_pow) {
-    uint32_t m = 0, lo = 0;   // lo: 0x7f800000 - bits of the smallest nonzero finite magnitude (larger = smaller; 0 = none): range_is_wide
-    auto see = [&](float f, float gt) {
-        const uint32_t b = (!GATED || gt > 0.0f) ? __float_as_uint(f) & 0x7fffffffu : 0u;
-        m = max(m, b);
-        lo = max(lo, (b - 1u < 0x7f7fffffu) ? 0x7f800000u - b : 0u);   // (b - 1 wraps for 0: zero, Inf and NaN do not count)
-    };
-    auto see4 = [&](const float4& v, const float4& gt) { see(v.x, gt.x); see(v.y, gt.y); see(v.z, gt.z); see(v.w, gt.w); };
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    const uintptr_t both = reinterpret_cast<uintptr_t>(p) | (GATED ? reinterpret_cast<uintptr_t>(gate) : 0);
-    if ((both & 15) == 0) {   // (scalar loads: 85 us for 2 x 60 MB)
-        const int64_t n4 = n >> 2;
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        const float4* g4 = reinterpret_cast<const float4*>(gate);
-        const float4 one = {1.f, 1.f, 1.f, 1.f};
-        int64_t k = gid;
-        for (; k + 3 * gsz < n4; k += 4 * gsz) {
-            const float4 v0 = p4[k], v1 = p4[k + gsz], v2 = p4[k + 2 * gsz], v3 = p4[k + 3 * gsz];
-            if constexpr (GATED) {
-                const float4 t0 = g4[k], t1 = g4[k + gsz], t2 = g4[k + 2 * gsz], t3 = g4[k + 3 * gsz];
-                see4(v0, t0); see4(v1, t1); see4(v2, t2); see4(v3, t3);
-            } else { see4(v0, one); see4(v1, one); see4(v2, one); see4(v3, one); }
-        }
-        for (; k < n4; k += gsz) see4(p4[k], GATED ? g4[k] : one);
-        for (int64_t t = (n4 << 2) + gid; t < n; t += gsz) see(p[t], GATED ? gate[t] : 1.f);
-    } else {
-        for (int64_t k = gid; k < n; k += gsz) see(p[k], GATED ? gate[k] : 1.f);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { m = max(m, (uint32_t)__shfl_xor((int)m, off)); lo = max(lo, (uint32_t)__shfl_xor((int)lo, off)); }
-    // one atomic per workgroup: a single word saturates near 88 atomics/us (MI355X_MICROARCH.md
-    // "dequeue"), so per-wave atomics from a 2048-block grid alone cost ~90 us
-    __shared__ uint32_t wmax[kAbsmaxThreads / 64], wlo[kAbsmaxThreads / 64];
-    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wlo[threadIdx.x >> 6] = lo; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nwv = (int)(blockDim.x >> 6);
-        m = 0; lo = 0;
-        for (int w = 0; w < nwv; ++w) { m = max(m, wmax[w]); lo = max(lo, wlo[w]); }
-        if (m) atomicMax(out, m);
-        if (lo && out_lo) atomicMax(out_lo, lo);
-        if (out_lo && blockIdx.x == 0) { out_lo[2] = guard_cap; if (guard_pow) out_lo[5] = guard_pow; }   // (words k + 4 and, for X, 7: range_is_wide)
-    }
-}
-__global__ __launch_bounds__(kAbsmaxThreads) void absmax_kernel(const float* __restrict__ p, int64_t n,
-                                                                uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
-    absmax_body<false>(p, nullptr, n, out, out_lo, guard_cap, guard_pow);
-}
-// absmax over the elements a gate lets through (gate > 0): the ReLU backward mask applied while staging dY
-__global__ __launch_bounds__(kAbsmaxThreads) void absmax_gated_kernel(const float* __restrict__ p, const float* __restrict__ gate, int64_t n, uint32_t* out, uint32_t* out_lo, uint32_t guard_cap, uint32_t guard_pow) {
-    absmax_body<true>(p, gate, n, out, out_lo, guard_cap, guard_pow);
-}
-
-// One thread per 16-byte output chunk (8 halves).  Rows: N real + 1 all-zero sentinel row that
-// padding columns of the tile stream point at (the reference zero-fills those, :423-424).
-template <bool VEC>
-__global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ X, int32_t N,
-                                                      int32_t D, int32_t Dpad, int32_t pitch,
-                                                      _Float16* __restrict__ X16,
-                                                      const uint32_t* __restrict__ hdr, const float* __restrict__ G = nullptr, int64_t ldx = 0,
-                                                      uint32_t* __restrict__ tiny = nullptr, uint32_t* __restrict__ dirty_hdr = nullptr) {
-    if (ldx == 0) ldx = D;   // row stride of X (and G) in floats: > D when X is a column block of a wider matrix
-    const int cpr = Dpad >> 3;
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = ((int64_t)N + 1) * cpr;
-    if (q >= total) return;
-    const int64_t row = q / cpr;
-    const int d0 = (int)(q - row * cpr) * 8;
-    const float s = pow2f(scale_exp_from_bits(hdr[0]));
-    half8 o;
-    uint32_t nt = 0;   // elements that lose bits in the image (range guard): nonzero, below fp16's normal range once scaled
-    if (row < N && VEC && d0 + 8 <= D) {
-        const float4* src = reinterpret_cast<const float4*>(X + row * ldx + d0);
-        const float4 a = src[0], b = src[1];
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool on = !G || G[row * ldx + d0 + j] > 0.0f;
-            o[j] = on ? to_half_rna(v[j] * s) : (_Float16)0.0f;
-            nt += on ? is_tiny(v[j], s) : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = d0 + j;
-            const bool on = row < N && d < D && (!G || G[row * ldx + d] > 0.0f);
-            const float v = on ? X[row * ldx + d] : 0.0f;
-            o[j] = to_half_rna(v * s);
-            nt += is_tiny(v, s);
-        }
-    }
-    *reinterpret_cast<half8*>(X16 + row * pitch + d0) = o;
-    note_dirty_row(dirty_hdr, nt, row);
-    count_tiny(tiny, nt);
-}
-
-// ------------------------------------------------------------------------------------------
-// SpMM:  Y[window] = A_tile-stream * X16
-// ------------------------------------------------------------------------------------------
-struct SpmmArgs {
-    const int64_t* wb_ptr;
-    const int32_t* order;
-    const int32_t* cols;
-    const uint32_t* mask;
-    const int32_t* ebase;
-    const _Float16* x16;
-    const float* edge_val;
-    const uint32_t* hdr;
-    float* y;
-    int32_t N, D, stride, chunk0;
-    int64_t E;
-    int32_t xrows;   // rows of X16 including the zero sentinel row
-    int32_t relu;    // fused epilogue: Y = max(A X, 0) (binary SpMM only)
-    int32_t ldy;     // row stride of Y in floats (== D unless this call is one column block of a wider matrix)
-    int32_t big;     // the fp16 image is 4 GB or more: gathers use 64-bit lane addresses (a buffer descriptor's index * stride wraps at 2^32)
-    const float* w;  // f3: dense update fused behind the aggregation, Y[N, dout] = (A X) W with W [D, dout] fp32 row-major (nullptr: Y = A X)
-    int32_t dout;
-    int32_t accumulate;   // Y += A X: the cold remainder of a plan whose dense part the LDS-resident kernel has already stored
-};
-
-// ---- f3: the dense update in the aggregation kernel's epilogue (gnn_conv.py:92-97: X' = TCGNN.forward(X); X' = mm(X', W)).
-// A window's aggregated rows Acc[16][din] (fp32, true scale) sit in LDS scratch `acc_lds` (row-major, leading dimension ldp, odd:
-// conflict-free column reads); one wavefront multiplies them by the W columns of output tile t on the fp32 matrix pipe
-// (v_mfma_f32_16x16x4_f32: exact fp32 fma chain, the precision of the torch.mm it replaces) and returns C[row 4g+ii][col 16t+i].
-// W (<= 128 x 128 floats) is read through the caches: every window re-reads the same 64 KB at most.
-__device__ __forceinline__ floatx4 dense_update_tile(const float* acc_lds, int ldp, int din, const float* __restrict__ w, int k0, int dout,
-                                                     int t, int g, int i) {
-    floatx4 c = {0.f, 0.f, 0.f, 0.f};
-    const int n = 16 * t + i;
-    for (int kk = 0; kk < din; kk += 4) {
-        const int k = kk + g;
-        const float av = k < din ? acc_lds[i * ldp + k] : 0.0f;
-        const float bv = (k < din && n < dout) ? w[(int64_t)(k0 + k) * dout + n] : 0.0f;
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
-    }
-    return c;
-}
-
-// ---- memory pipeline discipline -----------------------------------------------------------------
-// With an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of ANY ordinary load result and
-// before any LDS read it can see (cdna_hip_programming.md 5, trap (b)) - that drained the next
-// tile's gather in the first version of these kernels.  Hiding loads in inline asm avoids the
-// drain, but a VGPR with an asm load in flight is a trap of its own: the register allocator may
-// copy it before our wait (found by tools/audit_hidden_loads.py: `v_mov_b32 v2, v3` scheduled
-// above the s_waitcnt).  So the rule here is: NO VGPR EVER HAS A LOAD IN FLIGHT OUTSIDE ONE ASM
-// STATEMENT.
-//   * global -> LDS: LDS-DMA builtins only (per-tile metadata, gathered rows, edge values, SDDMM
-//     operands).  No VGPR destination; in flight across loop iterations; retired by wait_vm0().
-//   * LDS -> VGPR: the generated blocks of tcgnn_lds_blocks.inc, whose s_waitcnt lgkmcnt(0) is in
-//     the same asm statement as the reads (early-clobber outputs).
-typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
-#include "tcgnn_lds_blocks.inc"
-
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// LDS store issued from asm (no destination register, so nothing can be in flight into a VGPR);
-// LDS operations of one wavefront execute in order, a later block read sees the data.
-// (mask & a) | (~mask & b) in one instruction (hipcc otherwise spends a compare and a select on the loop-invariant b)
-__device__ __forceinline__ uint32_t bitfield_select(uint32_t mask, uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void lds_write_b32(uint32_t lds_byte_addr, float v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void lds_ids_block(const uint32_t* ad, uint32_t* v, uint32_t qaddr, uintx4& q) {
-    if constexpr (N == 1) lds_ids_block1(ad, v, qaddr, q);
-    else if constexpr (N == 2) lds_ids_block2(ad, v, qaddr, q);
-    else if constexpr (N == 3) lds_ids_block3(ad, v, qaddr, q);
-    else if constexpr (N == 4) lds_ids_block4(ad, v, qaddr, q);
-    else if constexpr (N == 5) lds_ids_block5(ad, v, qaddr, q);
-    else if constexpr (N == 6) lds_ids_block6(ad, v, qaddr, q);
-    else if constexpr (N == 7) lds_ids_block7(ad, v, qaddr, q);
-    else if constexpr (N == 8) lds_ids_block8(ad, v, qaddr, q);
-    else if constexpr (N == 9) lds_ids_block9(ad, v, qaddr, q);
-    else lds_ids_block10(ad, v, qaddr, q);
-}
-template <int N, int OFF> __device__ __forceinline__ void lds_q_block(const uint32_t* ad, uintx4* q) {
-    if constexpr (N == 1) lds_q_block1<OFF>(ad, q);
-    else if constexpr (N == 2) lds_q_block2<OFF>(ad, q);
-    else if constexpr (N == 3) lds_q_block3<OFF>(ad, q);
-    else if constexpr (N == 4) lds_q_block4<OFF>(ad, q);
-    else if constexpr (N == 5) lds_q_block5<OFF>(ad, q);
-    else if constexpr (N == 6) lds_q_block6<OFF>(ad, q);
-    else if constexpr (N == 7) lds_q_block7<OFF>(ad, q);
-    else if constexpr (N == 8) lds_q_block8<OFF>(ad, q);
-    else if constexpr (N == 9) lds_q_block9<OFF>(ad, q);
-    else lds_q_block10<OFF>(ad, q);
-}
-template <int K, int OFF> __device__ __forceinline__ void lds_tr_block(const uint32_t (*ad)[2], half4* lo, half4* hi) {
-    if constexpr (K == 1) lds_tr_block1<OFF>(ad, lo, hi);
-    else if constexpr (K == 2) lds_tr_block2<OFF>(ad, lo, hi);
-    else if constexpr (K == 3) lds_tr_block3<OFF>(ad, lo, hi);
-    else if constexpr (K == 4) lds_tr_block4<OFF>(ad, lo, hi);
-    else { lds_tr_block4<OFF>(ad, lo, hi); lds_tr_block<K - 4, OFF>(ad + 4, lo + 4, hi + 4); }
-}
-
-// 256-entry table: byte of adjacency bits -> the eight fp16 {0,1} values of a binary A fragment.
-// One LDS read replaces ~28 VALU instructions per tile.
-__device__ __forceinline__ void fill_afrag_table(char* tab) {
-    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-        half8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ((e >> j) & 1) ? (_Float16)1.0f : (_Float16)0.0f;
-        *reinterpret_cast<half8*>(tab + e * 16) = v;
-    }
-}
-
-// Per-tile metadata travels as ONE 256-byte DMA: lane l < 32 fetches cols[t][l], lanes 32..47
-// mask[t][l-32], lanes 48..63 ebase[t][l-48]; it lands lane-linear in a per-wavefront pad.
-#ifndef TCGNN_NT_STORES
-#define TCGNN_NT_STORES 0   // 1: the fused AGNN kernel's score / slice-addend stores are non-temporal (A/B experiments)
-#endif
-template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) {
-#if TCGNN_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-#ifndef TCGNN_META_AUX
-#define TCGNN_META_AUX 0   // cache policy of the metadata stream (bit 1 = nt): A/B experiments
-#endif
-struct MetaSource {
-    const char* base;   // this lane's element of tile 0
-    int shift;          // log2(bytes per tile) of the array this lane reads
-    __device__ __forceinline__ MetaSource(const int32_t* cols, const uint32_t* mask, const int32_t* ebase, int lane) {
-        if (lane < 32) { base = reinterpret_cast<const char*>(cols + lane); shift = 7; }
-        else if (lane < 48) { base = reinterpret_cast<const char*>(mask + (lane - 32)); shift = 6; }
-        else { base = reinterpret_cast<const char*>(ebase + (lane - 48)); shift = 6; }
-    }
-    __device__ __forceinline__ void dma(int64_t t, uint32_t pad_lds) const {
-        const char* src = base + (t << shift);
-        __builtin_amdgcn_global_load_lds((GLB_AS const void*)src, (LDS_AS void*)(uintptr_t)pad_lds, 4, 0, TCGNN_META_AUX);
-    }
-};
-static constexpr int kPadBytes = 256;
-
-// eight 4-byte LDS reads at per-lane addresses, retired before anything else is issued (agnn_kernel backward: the saved scores of
-// this lane's eight tile columns; TileWalker: its edge values - picked out of the lane's run by address instead of by a cascade of selects)
-__device__ __forceinline__ void lds_read8_b32(const uint32_t (&ad)[8], uint32_t (&v)[8]) {
-    asm volatile("ds_read_b32 %0, %8\n\t"
-                 "ds_read_b32 %1, %9\n\t"
-                 "ds_read_b32 %2, %10\n\t"
-                 "ds_read_b32 %3, %11\n\t"
-                 "ds_read_b32 %4, %12\n\t"
-                 "ds_read_b32 %5, %13\n\t"
-                 "ds_read_b32 %6, %14\n\t"
-                 "ds_read_b32 %7, %15\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-                 : "memory");
-}
-
-// Per-lane constants and the software-pipelined walk over a run of wide blocks, shared by the
-// per-window kernel (run = every WAVES-th tile of one window) and the range-blocked kernel
-// (run = the tiles of one window inside one column range).
-template <int NT, bool VAL>
-struct TileWalker {
-    static constexpr int TILE_BYTES = NT * 1024;
-    static constexpr int WAVE_LDS = 2 * TILE_BYTES + kPadBytes + (VAL ? 2048 : 0);  // two tile buffers, metadata pad, edge values (2 x 4 per lane)
-    static constexpr int NIDS = NT + 1 + (VAL ? 1 : 0);
-    using Img = TileImage<NT>;
-    const SpmmArgs& a;
-    __amdgpu_buffer_rsrc_t xrsrc; // X16 as a structured buffer: record = one fp16 row (pitch bytes);
-                                  // the gather address row*pitch + offset is formed by the hardware
-    MetaSource meta;
-    uint32_t ring, pad, vpad, atab; // LDS byte addresses: tile buffers, metadata pad, edge-value pad, A table
-    int lane, g, i;
-    uint32_t doff[NT];            // byte offset inside a gathered row: first feature column of the pass + 16-byte piece
-    uint32_t idaddr[NIDS];        // LDS addresses in the pad: row id of DMA k for this lane, mask word, edge offset
-    uint32_t raddr[NT][2];        // LDS address (buffer 0) this lane hands ds_read_b64_tr_b16 for slice s, K half h
-    float sa;                     // edge-value scale (VAL)
-
-    __device__ __forceinline__ TileWalker(const SpmmArgs& args, char* wave_lds, char* atab_ptr, int coloff, float sa_)
-        : a(args), meta(args.cols, args.mask, args.ebase, threadIdx.x & 63), sa(sa_) {
-        lane = threadIdx.x & 63;
-        g = lane >> 4;
-        i = lane & 15;
-        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.xrows, 0x00020000);
-        ring = (uint32_t)(uintptr_t)((LDS_AS char*)wave_lds);
-        pad = ring + 2 * TILE_BYTES;
-        vpad = pad + kPadBytes;
-        atab = (uint32_t)(uintptr_t)((LDS_AS char*)atab_ptr);
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            int row, c;
-            Img::unslot(k * 64 + lane, row, c);
-            idaddr[k] = pad + (uint32_t)row * 4u;
-            doff[k] = (uint32_t)(coloff * 2 + c * 16);
-        }
-        idaddr[NT] = pad + 128u + (uint32_t)i * 4u;
-        if constexpr (VAL) idaddr[NT + 1] = pad + 192u + (uint32_t)i * 4u;
-        // lane (g, i) receives K = 8g + 4h + {0..3} of column 16s + i when it points the transpose
-        // read at row 8g + 4h + (i >> 2), halves 16s + 4(i & 3) .. +3
-        const int rrow = 8 * g + (i >> 2);
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const int c = 2 * s + ((i >> 1) & 1);
-            raddr[s][0] = ring + (uint32_t)(Img::slot(rrow, c) * 16 + (i & 1) * 8);
-            raddr[s][1] = ring + (uint32_t)(Img::slot(rrow + 4, c) * 16 + (i & 1) * 8);
-        }
-    }
-
-    struct Cur {            // the tile being multiplied: its mask word, edge offset, value-window shift; wide: eight values fetched
-        uint32_t m, eb;
-        int shift;
-        bool wide;
-    };
-    template <int BUF> __device__ __forceinline__ void dma_gather(const uint32_t* cid) const {
-        if (a.big) {   // (wave-uniform: a kernel argument)
-            const char* const xb = reinterpret_cast<const char*>(a.x16);
-            const uint64_t pitchb = (uint64_t)a.stride * 2u;
-#pragma unroll
-            for (int k = 0; k < NT; ++k)
-                __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[k] * pitchb + doff[k]),
-                                                 (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16, 0, 0);
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < NT; ++k)
-            __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + BUF * TILE_BYTES + k * 1024), 16,
-                                                        (int)cid[k], (int)doff[k], 0, 0, 0);
-    }
-    // edge values of this lane's byte of row i: consecutive floats starting at the first edge of the byte (a row's edges inside
-    // eight columns are one run of the CSR), clamped so the read stays inside edge_val; they land in this lane's slot of the value
-    // pad.  Four cover the run almost always; when some lane's run is longer (hub rows: every second column is an edge) a second
-    // DMA fetches the next four - wave-uniform, decided from the mask.
-    __device__ __forceinline__ void dma_vals(Cur& c) const {
-        const int64_t e0 = (int64_t)c.eb + __popc(c.m & ((1u << (8 * g)) - 1u));
-        int64_t lo = e0 < a.E - 8 ? e0 : a.E - 8;
-        if (lo < 0) lo = 0;
-        c.shift = (int)(e0 - lo);
-        c.wide = a.E >= 8 && __any(__popc((c.m >> (8 * g)) & 0xffu) + c.shift > 4);
-        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo), (LDS_AS void*)(uintptr_t)vpad, 16, 0, 0);
-        if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.edge_val + lo + 4), (LDS_AS void*)(uintptr_t)(vpad + 1024u), 16, 0, 0);
-    }
-
-    template <int BUF> __device__ __forceinline__ void multiply(const Cur& cur, const uintx4& q, const uint32_t (&sv)[8], floatx4 (&acc)[NT]) const {
-        half8 af;
-        if constexpr (VAL) {
-            const uint32_t mb = (cur.m >> (8 * g)) & 0xffu;
-            const int nb = __popc(mb);
-            if (!cur.wide && __builtin_expect(__any(nb + cur.shift > 4), 0)) {
-                // (fewer than eight edges in the whole matrix) ordinary loads; the compiler drains the DMA queue for them
-                const int64_t e0 = (int64_t)cur.eb + __popc(cur.m & ((1u << (8 * g)) - 1u));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool on = (mb >> j) & 1u;
-                    const float v = on ? a.edge_val[e0 + __popc(mb & ((1u << j) - 1u))] * sa : 0.0f;
-                    af[j] = to_half_rna(v);
-                }
-            } else {
-                // sv[j]: the value of tile column j of my eight, read from the fetched run BY ADDRESS in stage() (r03: the cascade of
-                // selects over the fetched registers cost ~10 VALU instructions per column of a loop that is VALU-bound)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) af[j] = ((mb >> j) & 1u) ? to_half_rna(__uint_as_float(sv[j]) * sa) : (_Float16)0.0f;
-            }
-        } else {
-            af = __builtin_bit_cast(half8, q);   // table entry of this lane's adjacency byte
-        }
-        half4 lo[NT], hi[NT];
-        lds_tr_block<NT, BUF * TILE_BYTES>(raddr, lo, hi);
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[s], 0, 0, 0);
-        }
-    }
-
-    // One pipeline stage, tile t in tile buffer BUF.  On entry the DMA queue holds gather(t),
-    // [edge values(t)] and the metadata of the next tile; after ONE wait everything is read from LDS
-    // (ids of the next tile + A fragment or edge values of this one), the next gather, the next edge
-    // values and the metadata of the tile after that are issued, and tile t is multiplied underneath.
-    // Returns false when t was the last tile of the run.
-    template <int BUF>
-    __device__ __forceinline__ bool stage(int64_t& t, int64_t& tn, const int64_t te, const int64_t step, const int64_t t_after,
-                                          Cur& cur, floatx4 (&acc)[NT]) const {
-        wait_vm0();
-        uint32_t v[NIDS];
-        uintx4 q;
-        const uint32_t qaddr = VAL ? vpad + (uint32_t)lane * 16u : atab + (((cur.m >> (8 * g)) & 0xffu) << 4);
-        lds_ids_block<NIDS>(idaddr, v, qaddr, q);
-        [[maybe_unused]] uint32_t sv[8];
-        if constexpr (VAL) {   // (before the next tile's values overwrite the pad)
-            const uint32_t mb = (cur.m >> (8 * g)) & 0xffu, vbase = vpad + (uint32_t)lane * 16u;
-            uint32_t va = vbase + ((uint32_t)cur.shift << 2), ad[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                ad[j] = va;
-                va -= (uint32_t)((int32_t)(mb << (31 - j)) >> 31) << 2;                 // + 4 where the edge exists
-            }
-            if (cur.wide) {   // (wave-uniform: some lane's run crosses into the second block of four)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ad[j] += (((ad[j] - vbase) >> 4) & 1u) * 1008u;
-            }
-            lds_read8_b32(ad, sv);
-        }
-        const bool more = tn < te;
-        Cur nx;
-        nx.m = v[NT];
-        nx.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
-        nx.shift = 0;
-        nx.wide = false;
-        const int64_t tnn = tn + step;
-        if (more) {
-            dma_gather<BUF ^ 1>(v);
-            if constexpr (VAL) dma_vals(nx);
-            const int64_t tf = tnn < te ? tnn : t_after;   // metadata two tiles ahead; at the end of the run: the caller's next run
-            if (tf >= 0) meta.dma(tf, pad);
-        }
-        multiply<BUF>(cur, q, sv, acc);
-        cur = nx;
-        t = tn;
-        tn = tnn;
-        return more;
-    }
-
-    // acc += A(tiles t, t+step, ... < te) * X16 rows.  `pad_tile` is the tile whose metadata the pad
-    // holds (or has in flight) on entry, and on return; passing the caller's next run's first tile as
-    // t_after lets the last stage prefetch it.
-    __device__ __forceinline__ void walk(int64_t t, const int64_t te, const int64_t step, floatx4 (&acc)[NT], int64_t& pad_tile,
-                                         const int64_t t_after) const {
-        if (t >= te) return;
-        if (pad_tile != t) meta.dma(t, pad);
-        wait_vm0();
-        uint32_t v[NIDS];
-        uintx4 q;
-        lds_ids_block<NIDS>(idaddr, v, atab, q);   // (the 16-byte read is a dummy here)
-        Cur cur;
-        cur.m = v[NT];
-        cur.eb = VAL ? v[NT + (VAL ? 1 : 0)] : 0u;
-        cur.shift = 0;
-        cur.wide = false;
-        dma_gather<0>(v);
-        if constexpr (VAL) dma_vals(cur);
-        int64_t tn = t + step;
-        const int64_t tf = tn < te ? tn : t_after;
-        if (tf >= 0) meta.dma(tf, pad);
-        for (;;) {   // ping-pong over the two tile buffers: static LDS offsets, no register rotation
-            if (!stage<0>(t, tn, te, step, t_after, cur, acc)) break;
-            if (!stage<1>(t, tn, te, step, t_after, cur, acc)) break;
-        }
-        pad_tile = t_after;
-    }
-};
-
-// (second launch-bound argument = waves per SIMD: keeps the register budget at 128 / 256 so the
-// accumulators are allocated as VGPRs - with the default budget hipcc split them into AGPRs and
-// spent 24 v_accvgpr_* moves per tile shuffling them)
-template <int NT, int WAVES, bool VAL>
-__global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 4 : 2)) void spmm_kernel(const SpmmArgs a) {
-    if (VAL ? range_is_wide_val(a.hdr) : range_is_wide(a.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int w = a.order[blockIdx.x];
-    const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims; // first feature column of this pass
-    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
-    if (a.accumulate && !a.relu && tb == te) return;   // nothing to add to what the LDS-resident kernel stored
-    const int kx = scale_exp_from_bits(a.hdr[0]);
-    const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
-
-    floatx4 acc[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) acc[s] = floatx4{0.f, 0.f, 0.f, 0.f};
-    {
-        using TW = TileWalker<NT, VAL>;
-        char* atab = smem + WAVES * TW::WAVE_LDS;
-        fill_afrag_table(atab);
-        __syncthreads();
-        const TW tw(a, smem + wave * TW::WAVE_LDS, atab, coloff, pow2f(ka));
-        int64_t pad_tile = -1;
-        tw.walk(tb + wave, te, WAVES, acc, pad_tile, -1);
-    }
-
-    // ---- combine the wavefronts' partial sums in a fixed order and store
-    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f; // |kx + ka| may exceed 126: two factors
-    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
-    if constexpr (!VAL) {
-        if (a.w) {   // f3: Y[window] = (A X)[window] W   (one pass: the launcher only takes this path for D <= 128)
-            const int din = NT * 16;                               // (padding columns of X16 are zero)
-            const int ldp = din + 1;
-            float* accT = reinterpret_cast<float*>(smem) + (WAVES > 1 ? WAVES * NT * 256 : 0);   // behind the reduction buffer
-            __syncthreads(); // every wave is done with its ring
-            if constexpr (WAVES > 1) {
-                floatx4* red = reinterpret_cast<floatx4*>(smem);
-#pragma unroll
-                for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
-                __syncthreads();
-                for (int s = wave; s < NT; s += WAVES) {
-                    floatx4 v = red[s * 64 + lane];
-#pragma unroll
-                    for (int ww = 1; ww < WAVES; ++ww) {
-                        const floatx4 o = red[(ww * NT + s) * 64 + lane];
-                        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) accT[(4 * g + ii) * ldp + 16 * s + i] = v[ii] * inv1;
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < NT; ++s)
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) accT[(4 * g + ii) * ldp + 16 * s + i] = acc[s][ii] * inv1;
-            }
-            __syncthreads();
-            const int tiles = (a.dout + 15) >> 4;
-            for (int t = wave; t < tiles; t += WAVES) {
-                const floatx4 c = dense_update_tile(accT, ldp, a.D < din ? a.D : din, a.w, 0, a.dout, t, g, i);
-                const int colg = 16 * t + i;
-                if (colg < a.dout) {
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, c[ii]);
-                }
-            }
-            return;
-        }
-    }
-    if constexpr (WAVES > 1) {
-        __syncthreads(); // every wave is done with its ring
-        floatx4* red = reinterpret_cast<floatx4*>(smem);
-#pragma unroll
-        for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc[s];
-        __syncthreads();
-        for (int s = wave; s < NT; s += WAVES) {
-            floatx4 v = red[s * 64 + lane];
-#pragma unroll
-            for (int ww = 1; ww < WAVES; ++ww) {
-                const floatx4 o = red[(ww * NT + s) * 64 + lane];
-                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-            }
-            const int colg = coloff + 16 * s + i;
-            if (colg < a.D) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) {
-                        float* dst = a.y + (row0 + ii) * a.ldy + colg;
-                        *dst = relu_if(a.relu, v[ii] * inv1 * inv2 + (a.accumulate ? *dst : 0.0f));
-                    }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const int colg = coloff + 16 * s + i;
-            if (colg < a.D) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    if (row0 + ii < a.N) {
-                        float* dst = a.y + (row0 + ii) * a.ldy + colg;
-                        *dst = relu_if(a.relu, acc[s][ii] * inv1 * inv2 + (a.accumulate ? *dst : 0.0f));
-                    }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Range-blocked SpMM for graphs whose fp16 feature image does not fit the 4 MB per-XCD L2.
-//
-// PMC on the plain kernel (profiles/r01): 34 % L2 hit rate, 10 GB of fabric reads per launch for
-// 0.58 GB of algorithmic bytes - every window sweeps all of X16, and X16 (29.8 MB at Reddit D=64)
-// only fits the Infinity Cache, whose random-row gather rate (8.3 TB/s, tools/gather_bench) is
-// less than half the L2's (18 TB/s).  Here the columns are cut into R ranges of ~2 MB of X16.
-// A wavefront owns up to MAXW windows for its whole life and keeps their accumulators in
-// registers; it walks range 0 of all its windows, then range 1, ...  All resident wavefronts
-// start together and advance at the same average pace, so the rows being gathered at any moment
-// belong to one or two ranges and stay L2-resident on every XCD.  No partial sums leave the
-// registers, no atomics: the result is as deterministic as the plain kernel's.
-// ------------------------------------------------------------------------------------------
-struct SpmmBlockedArgs {
-    SpmmArgs base;
-    const uint32_t* bptr;
-    int32_t nbuckets, gsel, nranges, nw, ngroups;
-};
-
-__global__ void bucket_ptr_kernel(const int64_t* __restrict__ wb_ptr, const int32_t* __restrict__ cols, int32_t nw,
-                                  int32_t nbuckets, int32_t bucket_rows, uint32_t* bptr) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)nw * (nbuckets + 1)) return;
-    const int w = (int)(idx / (nbuckets + 1)), k = (int)(idx % (nbuckets + 1));
-    const int64_t tb = wb_ptr[w];
-    const int64_t n = wb_ptr[w + 1] - tb;
-    int64_t lo = 0, hi = n;
-    if (k == nbuckets) lo = n;
-    else
-        while (lo < hi) {  // tiles are ordered by column: first tile whose first column is in bucket >= k
-            const int64_t mid = (lo + hi) >> 1;
-            if (cols[(tb + mid) * kWbCols] / bucket_rows >= k) hi = mid; else lo = mid + 1;
-        }
-    bptr[idx] = (uint32_t)lo;
-}
-
-template <int NT, int MAXW, bool VAL>
-__global__ __launch_bounds__(256, (NT <= 4 ? 4 : 2)) void spmm_blocked_kernel(const SpmmBlockedArgs b) {
-    if (VAL ? range_is_wide_val(b.base.hdr) : range_is_wide(b.base.hdr, 0)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SpmmArgs& a = b.base;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int coloff = (a.chunk0 + (int)blockIdx.y) * kMaxChunkDims;
-    const int kx = scale_exp_from_bits(a.hdr[0]);
-    const int ka = VAL ? scale_exp_from_bits(a.hdr[1]) : 0;
-    const float inv1 = pow2f(-kx), inv2 = VAL ? pow2f(-ka) : 1.0f;
-    using TW = TileWalker<NT, VAL>;
-    char* atab = smem + 4 * TW::WAVE_LDS;
-    fill_afrag_table(atab);
-    __syncthreads();
-    const TW tw(a, smem + wave * TW::WAVE_LDS, atab, coloff, pow2f(ka));
-
-    const int gw = blockIdx.x * 4 + wave, gwn = gridDim.x * 4;
-    for (int grp = gw; grp < b.ngroups; grp += gwn) {
-        int wj[MAXW];
-        int64_t tbj[MAXW];
-        uint32_t done[MAXW];
-        floatx4 acc[MAXW][NT];
-#pragma unroll
-        for (int j = 0; j < MAXW; ++j) {
-            const int idx = grp + j * b.ngroups;   // strided picks from the heaviest-first order: balanced groups
-            wj[j] = idx < b.nw ? __builtin_amdgcn_readfirstlane(a.order[idx]) : -1;
-            tbj[j] = wj[j] >= 0 ? a.wb_ptr[wj[j]] : 0;
-            done[j] = 0;
-#pragma unroll
-            for (int s = 0; s < NT; ++s) acc[j][s] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-        int64_t pad_tile = -1;
-        // run q = (range r, window j); its bounds are looked up one run ahead so the walk can prefetch
-        // the ids of the next run's first tile while it finishes the current one
-        uint32_t nend[MAXW];
-#pragma unroll
-        for (int j = 0; j < MAXW; ++j) nend[j] = wj[j] >= 0 ? b.bptr[(int64_t)wj[j] * (b.nbuckets + 1) + b.gsel] : 0u;
-        for (int r = 0; r < b.nranges; ++r) {
-            uint32_t end[MAXW], after[MAXW];
-#pragma unroll
-            for (int j = 0; j < MAXW; ++j) {
-                end[j] = nend[j];
-                after[j] = (wj[j] >= 0 && r + 1 < b.nranges) ? b.bptr[(int64_t)wj[j] * (b.nbuckets + 1) + (int64_t)(r + 2) * b.gsel] : end[j];
-                nend[j] = after[j];
-            }
-#pragma unroll
-            for (int j = 0; j < MAXW; ++j) {
-                if (wj[j] < 0) continue;
-                // first tile of the next non-empty run: window j+1.. of this range, else window 0.. of the next
-                int64_t t_after = -1;
-#pragma unroll
-                for (int jj = MAXW - 1; jj >= 0; --jj)
-                    if (wj[jj] >= 0 && after[jj] > end[jj]) t_after = tbj[jj] + end[jj];
-#pragma unroll
-                for (int jj = MAXW - 1; jj > j; --jj)
-                    if (wj[jj] >= 0 && end[jj] > done[jj]) t_after = tbj[jj] + done[jj];
-                tw.walk(tbj[j] + done[j], tbj[j] + end[j], 1, acc[j], pad_tile, t_after);
-                done[j] = end[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < MAXW; ++j) {
-            if (wj[j] < 0) continue;
-            const int64_t row0 = (int64_t)wj[j] * kWinRows + 4 * g;
-#pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                const int colg = coloff + 16 * s + i;
-                if (colg < a.D) {
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-                        if (row0 + ii < a.N) a.y[(row0 + ii) * a.ldy + colg] = relu_if(a.relu, acc[j][s][ii] * inv1 * inv2);
-                }
-            }
-        }
-    }
-}
 
 #include "tcgnn_lds_spmm.inc"
 #include "tcgnn_lds_flat.inc"
 #include "tcgnn_lds_val.inc"
 
-// ------------------------------------------------------------------------------------------
-// SDDMM:  ef[e] = <X16[row e], X16[col e]>
-// ------------------------------------------------------------------------------------------
-struct SddmmArgs {
-    const int64_t* wb_ptr;
-    const int32_t* order;
-    const int32_t* cols;
-    const uint32_t* mask;
-    const int32_t* ebase;
-    const _Float16* x16;
-    const uint32_t* hdr;
-    float* ef;
-    int32_t N, Nc, row_off, Dpad, stride;
-    const int32_t* rowptr;
-    const uint32_t* bptr;       // range-blocked walk (nranges > 0)
-    int32_t nbuckets, gsel, nranges, nw;
-    int32_t big;                // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
-    int32_t xcd;                // range-major walk with XCD affinity: workgroup b (on XCD b % 8) takes the ranges r = b % 8, b % 8 + 8, ... only
-};
-static constexpr int kXcdCount = 8;   // workgroups are dealt to the XCDs round-robin in launch order
+#include "tcgnn_sddmm.inc"
 
-// LDS of one SDDMM wavefront: two operand buffers, the metadata pad, the output staging area
-// (16 rows x kSddmmStageCap floats) and 256 bytes of junk slots for lanes that have nothing to stage.
-static constexpr int kSddmmStageCap = 64;
-#ifndef TCGNN_SDDMM_NBUF
-#define TCGNN_SDDMM_NBUF(ks) ((ks) <= 2 ? 2 : 1)
-#endif
-// Operand buffers: two (gather of the next tile under the multiply of this one) up to D = 64; one beyond,
-// where LDS would otherwise allow a single workgroup per CU (latency is then hidden by wavefront count only).
-static constexpr int sddmm_nbuf(int ks) { return TCGNN_SDDMM_NBUF(ks); }
-static constexpr int sddmm_wave_lds(int ks) { return sddmm_nbuf(ks) * (2 * ks * 1024) + kPadBytes + 16 * kSddmmStageCap * 4 + 256; }
+#include "tcgnn_agnn.inc"
 
-// KS = number of 32-wide k steps (D <= 32*KS <= 128).  The 16 window rows (MFMA A operand) stay in
-// registers.  Neighbour rows are the B operand, which for X * X^T is contiguous per lane: lane
-// (i, g) needs halves 32*ks + 8g .. +7 of neighbour row i.  Each lane DMAs exactly those 16 bytes
-// (structured-buffer addressing: row id * pitch + offset formed by the hardware) into its own LDS
-// slot and reads the slot back - LDS is a per-lane landing pad, trivially conflict-free - so the
-// gather of the NEXT tile (both 16-column halves) is in flight while the current one is multiplied
-// and scattered, without any VGPR holding a load in flight (see "memory pipeline discipline").
-template <int KS, int WAVES, bool BLOCKED>
-__global__ __launch_bounds__(WAVES * 64, (KS <= 2 ? 4 : 3)) void sddmm_kernel(const SddmmArgs a) {
-    if (wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BUF_BYTES = 2 * KS * 1024;               // both halves of one tile
-    constexpr int WAVE_LDS = sddmm_wave_lds(KS);
-    constexpr int CAP = kSddmmStageCap;                    // staged outputs per row before a flush
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int64_t stride = a.stride;
-    const int kx = scale_exp_from_bits(a.hdr[0]);
-    // ef = acc * 2^(-2kx); one multiply unless 2kx leaves the fp32 exponent range (then two)
-    const bool two_step = kx > 63 || kx < -63;
-    const float inv_a = two_step ? pow2f(-kx) : pow2f(-2 * kx), inv_b = two_step ? pow2f(-kx) : 1.0f;
-    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-    const uint32_t below[2] = {(1u << i) - 1u, (1u << (16 + i)) - 1u};   // condensed columns left of mine, per half
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
-    const MetaSource meta(a.cols, a.mask, a.ebase, lane);
-    const uint32_t ring = (uint32_t)(uintptr_t)((LDS_AS char*)(smem + wave * WAVE_LDS));
-    const uint32_t pad = ring + sddmm_nbuf(KS) * BUF_BYTES;
-    // a lane whose k slice lies past Dpad fetches slice 0 instead (valid memory) and is zeroed at use
-    uint32_t boff[KS];
-    bool bok[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { bok[ks] = ks * 32 + 8 * g < a.Dpad; boff[ks] = bok[ks] ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u; }
-    // WL (KS = 2, rows of one 128-byte line; r03): whole-line gathers, as in agnn_kernel - instruction q takes the eight rows of tile
-    // columns 8q .. 8q+7 (lane L: row slot L >> 3, the chunk that belongs at position L & 7) into block q, row-major; chunk c of row
-    // slot rho lies at position c ^ 2 (rho >> 1), which spreads the sixteen lanes of every ds_read_b128 lane group of the operand
-    // reads (row i of half sub = row slot i & 7 of block 2 sub + (i >> 3), chunk 4 ks + g) over the sixteen 16-byte bank slots.
-    // KS = 4 (256-byte rows): four rows per instruction, eight instructions, tile column tau in row slot tau & 3 of block tau >> 2,
-    // chunk c at position c ^ (4 (q & 3) + rho).  (KS = 3: the layout above, see agnn_kernel.)
-    constexpr bool WL = KS == 2 || KS == 4;
-    constexpr int RB = KS == 2 ? 128 : 256, RPI = 1024 / RB, NI = WL ? 32 / RPI : 2, CPR = RB / 16;
-    constexpr int NIDR = NI;                                                                      // row ids this lane reads per tile
-    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t {
-        if constexpr (KS == 2) return 2u * (rho >> 1);
-        else return 4u * (q & 3u) + rho;
-    };
-    uint32_t idaddr[NIDR];
-    if constexpr (WL) {
-#pragma unroll
-        for (int q = 0; q < NI; ++q) idaddr[q] = pad + (uint32_t)(RPI * q + lane / CPR) * 4u;
-    } else { idaddr[0] = pad + (uint32_t)i * 4u; idaddr[1] = pad + 64u + (uint32_t)i * 4u; }      // row ids of both halves
-    [[maybe_unused]] uint32_t choff[WL ? NI : 1];                                                 // WL: byte offset of my chunk inside the rows instruction q fetches
-    if constexpr (WL) {
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const uint32_t c = (uint32_t)(lane % CPR) ^ wl_sw((uint32_t)(lane / CPR), (uint32_t)q);
-            choff[q] = ((int)(c * 8u) < a.Dpad) ? c * 16u : 0u;
-        }
-    }
-    uint32_t qaddr[1 + 2 * KS];                                                                   // edge offsets, then my landing slots
-    qaddr[0] = pad + 192u + 16u * (uint32_t)g;
-#pragma unroll
-    for (int k = 0; k < 2 * KS; ++k) {
-        if constexpr (WL) {   // row i of half sub = tile column 16 sub + i
-            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS), tau = 16u * sub + (uint32_t)i, q = tau / RPI, rho = tau % RPI;
-            qaddr[1 + k] = ring + q * 1024u + rho * (uint32_t)RB + (((4u * ks + (uint32_t)g) ^ wl_sw(rho, q)) * 16u);
-        } else qaddr[1 + k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-    }
-    const uint32_t m4addr = pad + 128u + 16u * (uint32_t)g;
-    // Output staging.  PMC (profiles/r01): scattering every result with its own 4-byte store costs
-    // 7.6e7 L2 write requests per launch on top of the 1.25e8 gather reads, and the kernel runs at the
-    // L2 request-rate ceiling.  A wavefront walks CONSECUTIVE tiles, and a row's edges in consecutive
-    // tiles are consecutive in ef, so results are staged per row in LDS and each row is flushed as one
-    // contiguous store (about one store per tile instead of eight, ~10x fewer write requests).
-    const uint32_t stg = pad + kPadBytes;
-    const uint32_t junk = stg + 16u * CAP * 4u + (uint32_t)lane * 4u;
-    const uint32_t stg_row[4] = {stg + (uint32_t)(4 * g + 0) * CAP * 4u, stg + (uint32_t)(4 * g + 1) * CAP * 4u,
-                                 stg + (uint32_t)(4 * g + 2) * CAP * 4u, stg + (uint32_t)(4 * g + 3) * CAP * 4u};
-    const uint32_t flush_base = stg + (uint32_t)lane * 4u;        // lane j reads the j-th staged result of every row
-
-  // one run: CONSECUTIVE tiles t .. te-1 of window w (step must be 1: the staging relies on it)
-  auto run = [&](const int w, int64_t t, const int64_t te, const int64_t step) {
-    if (t >= te) return;
-    // A operand: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
-    int64_t arow = (int64_t)w * kWinRows + i;
-    arow = arow < a.N ? arow + a.row_off : a.Nc;
-    const _Float16* ap = a.x16 + arow * stride + 8 * g;
-    half8 af[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-    // edges of this window live in ef[e_w0 .. ): 32-bit offsets from a wave-uniform base
-    const int64_t wrow = (int64_t)w * kWinRows;
-    const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
-    char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
-    bool flush_pending = false;
-    uint32_t cnt[4] = {0u, 0u, 0u, 0u};                          // staged results of rows 4g .. 4g+3
-    uint32_t rstart[4] = {~0u, ~0u, ~0u, ~0u};                   // window-relative ef position of each row's first staged result
-    auto flush = [&]() {
-        uint32_t vals[16];
-        lds_rows_block8<CAP * 4, 0>(flush_base, vals);
-        lds_rows_block8<CAP * 4, 8>(flush_base, vals + 8);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt[r & 3], 16 * (r >> 2));
-            const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart[r & 3], 16 * (r >> 2));
-            if ((uint32_t)lane < c_r) *reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)) = vals[r];
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) { cnt[ii] = 0u; rstart[ii] = ~0u; }
-    };
-
-    auto dma_b = [&](const uint32_t* cid, int bufbase) {
-        if constexpr (WL) {
-            if (a.big) {
-                const char* const xb = reinterpret_cast<const char*>(a.x16);
-#pragma unroll
-                for (int q = 0; q < NI; ++q)
-                    __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[q] * (uint64_t)(stride * 2) + choff[q]),
-                                                     (LDS_AS void*)(uintptr_t)(ring + bufbase + q * 1024), 16, 0, 0);
-                return;
-            }
-#pragma unroll
-            for (int q = 0; q < NI; ++q)
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + bufbase + q * 1024), 16, (int)cid[q], (int)choff[q], 0, 0, 0);
-            return;
-        }
-        if (a.big) {
-            const char* const xb = reinterpret_cast<const char*>(a.x16);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[sub] * (uint64_t)(stride * 2) + boff[ks]),
-                                                     (LDS_AS void*)(uintptr_t)(ring + bufbase + (sub * KS + ks) * 1024), 16, 0, 0);
-            return;
-        }
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + bufbase + (sub * KS + ks) * 1024), 16,
-                                                            (int)cid[sub], (int)boff[ks], 0, 0, 0);
-    };
-    struct Cur { uintx4 m4, eb4; };
-    auto stage = [&](auto BUFC, Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
-        constexpr int BUF = decltype(BUFC)::value;
-        wait_vm0();
-        uint32_t cid[NIDR];
-        uintx4 m4n, q[1 + 2 * KS];
-        lds_ids_block<NIDR>(idaddr, cid, m4addr, m4n);             // ids + masks of the next tile
-        constexpr int NB = sddmm_nbuf(KS);
-        lds_q_block<1 + 2 * KS, (NB == 2 ? BUF : 0) * BUF_BYTES>(qaddr, q);   // its edge offsets, and this tile's operands
-        const bool more = tn < te;
-        const int64_t tnn = tn + step;
-        if (more) {
-            dma_b(cid, (NB == 2 ? (BUF ^ 1) : 0) * BUF_BYTES);   // (single buffer: its reads above have completed)
-            if (tnn < te) meta.dma(tnn, pad);
-        }
-        // A flush decided at the end of the previous tile is issued HERE, right behind the gather: its stores then have as
-        // long to complete as the gather before the next wait (issued after the multiply they held that wait up).
-        if (flush_pending) { flush(); flush_pending = false; }
-        // ---- tile tcur
-        const uint32_t mm[4] = {cur.m4[0], cur.m4[1], cur.m4[2], cur.m4[3]};
-        const uint32_t e0 = (uint32_t)e_w0;   // window-relative edge positions (a window holds far fewer than 2^32 edges)
-        const uint32_t rbase[4] = {cur.eb4[0] - e0, cur.eb4[1] - e0, cur.eb4[2] - e0, cur.eb4[3] - e0};
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const uint32_t anyrow = ((mm[0] | mm[1] | mm[2] | mm[3]) >> (16 * sub)) & 0xffffu;
-            if (__any(anyrow != 0u)) {              // skip a 16-column half no edge lands in
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    // (a lane whose k slice lies past Dpad holds zeros in af: whatever it fetched for B is multiplied away)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], __builtin_bit_cast(half8, q[1 + sub * KS + ks]), acc, 0, 0, 0);
-                }
-                // C[row 4g+ii][col i] -> staged at the row's next free slot if the edge exists
-                const int bit = 16 * sub + i;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const bool on = (mm[ii] >> bit) & 1u;
-                    const uint32_t pos = cnt[ii] + (uint32_t)__popc(mm[ii] & below[sub]);
-                    float v = acc[ii] * inv_a;
-                    if (two_step) v *= inv_b;
-                    lds_write_b32(on ? stg_row[ii] + (pos << 2) : junk, v);
-                }
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            if (rstart[ii] == ~0u && mm[ii] != 0u) rstart[ii] = rbase[ii];
-            cnt[ii] += (uint32_t)__popc(mm[ii]);
-        }
-        // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
-        const uint32_t fullest = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
-        if (!more) flush();
-        else flush_pending = __any(fullest > (uint32_t)(CAP - 32));
-        cur.m4 = m4n;
-        cur.eb4 = q[0];
-        tcur = tn;
-        tn = tnn;
-        return more;
-    };
-
-    // prologue: metadata of the first tile, its operands, metadata of the second
-    meta.dma(t, pad);
-    wait_vm0();
-    Cur cur;
-    {
-        uint32_t cid[NIDR];
-        uintx4 e4[1];
-        lds_ids_block<NIDR>(idaddr, cid, m4addr, cur.m4);
-        lds_q_block<1, 0>(qaddr, e4);
-        cur.eb4 = e4[0];
-        dma_b(cid, 0);
-    }
-    int64_t tn = t + step;
-    if (tn < te) meta.dma(tn, pad);
-    for (;;) {
-        if (!stage(std::integral_constant<int, 0>{}, cur, t, tn)) break;
-        if (!stage(std::integral_constant<int, 1>{}, cur, t, tn)) break;
-    }
-    wait_vm0();   // the run's last stores are retired before the next run reuses pad and slots
-  };
-
-    if constexpr (BLOCKED) {
-        // persistent wavefronts take (column range, window) items in range-major order: at any moment
-        // the whole chip gathers from one or two ranges of X16, which stay L2-resident
-        if (a.xcd) {
-            // XCD affinity (r03, after the whole-line gathers made an L2 hit worth twice a miss): the workgroups of XCD x gather from
-            // the ranges x, x + 8, ... only, one after the other - that XCD's L2 is asked for an eighth of the image, a range or two of
-            // it at a time, instead of every range every other XCD is walking as well.  Every edge lies in exactly one range, so
-            // nothing is added up afterwards and the scores are bit for bit those of the other walks.
-            const int x = (int)(blockIdx.x % (unsigned)kXcdCount);
-            const int64_t items_x = (int64_t)(a.nranges / kXcdCount) * a.nw, lstride = (int64_t)(gridDim.x / (unsigned)kXcdCount) * WAVES;
-            for (int64_t q = (int64_t)(blockIdx.x / (unsigned)kXcdCount) * WAVES + wave; q < items_x; q += lstride) {
-                const int rr = (int)(q / a.nw), r = x + kXcdCount * rr;
-                const int w = __builtin_amdgcn_readfirstlane(a.order[q - (int64_t)rr * a.nw]);
-                const int64_t tb = a.wb_ptr[w];
-                const uint32_t* bp = a.bptr + (int64_t)w * (a.nbuckets + 1);
-                run(w, tb + bp[r * a.gsel], tb + bp[(r + 1) * a.gsel], 1);
-            }
-            return;
-        }
-        const int64_t items = (int64_t)a.nranges * a.nw;
-        for (int64_t q = (int64_t)blockIdx.x * WAVES + wave; q < items; q += (int64_t)gridDim.x * WAVES) {
-            const int r = (int)(q / a.nw);
-            const int w = __builtin_amdgcn_readfirstlane(a.order[q - (int64_t)r * a.nw]);
-            const int64_t tb = a.wb_ptr[w];
-            const uint32_t* bp = a.bptr + (int64_t)w * (a.nbuckets + 1);
-            run(w, tb + bp[r * a.gsel], tb + bp[(r + 1) * a.gsel], 1);
-        }
-    } else {
-        const int w = a.order[blockIdx.x];
-        const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
-        const int64_t chunk = (te - tb + WAVES - 1) / WAVES;       // contiguous share of this wavefront
-        const int64_t t0 = tb + wave * chunk;
-        run(w, t0, t0 + chunk < te ? t0 + chunk : te, 1);
-    }
-}
-
-// Run-time-K variant for D > 128: window rows are re-read per tile (L1-resident), ordinary loads.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void sddmm_wide_kernel(const SddmmArgs a) {
-    if (wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int w = a.order[blockIdx.x];
-    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
-    const int64_t stride = a.stride;
-    const float inv = pow2f(-scale_exp_from_bits(a.hdr[0]));
-    const int ksteps = (a.Dpad + 31) >> 5;
-    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t arow = (int64_t)w * kWinRows + i;
-    arow = arow < a.N ? arow + a.row_off : a.Nc;
-    const _Float16* ap = a.x16 + arow * stride + 8 * g;
-    for (int64_t t = tb + wave; t < te; t += WAVES) {
-        const uint4 m4 = *reinterpret_cast<const uint4*>(a.mask + t * kWinRows + 4 * g);
-        const int4 eb4 = *reinterpret_cast<const int4*>(a.ebase + t * kWinRows + 4 * g);
-        const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
-        const int ee[4] = {eb4.x, eb4.y, eb4.z, eb4.w};
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const uint32_t anyrow = ((m4.x | m4.y | m4.z | m4.w) >> (16 * sub)) & 0xffffu;
-            if (!__any(anyrow != 0u)) continue;
-            const int cid = a.cols[t * kWbCols + 16 * sub + i];
-            const _Float16* bp = a.x16 + (int64_t)cid * stride + 8 * g;
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const bool ok = ks * 32 + 8 * g < a.Dpad;
-                const half8 av = ok ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-                const half8 bf = ok ? *reinterpret_cast<const half8*>(bp + ks * 32) : hz;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bf, acc, 0, 0, 0);
-            }
-            const int bit = 16 * sub + i;
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                if ((mm[ii] >> bit) & 1u) {
-                    const int64_t e = (int64_t)ee[ii] + __popc(mm[ii] & ((1u << bit) - 1u));
-                    a.ef[e] = acc[ii] * inv * inv;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused AGNN products: one gather of a tile's 32 neighbour rows feeds BOTH the edge scores
-// (SDDMM) and the edge-weighted aggregation (SpMM), which the AGNN layer always wants together.
-//
-// Per tile:   S^T = Xc * Xw^T   (MFMA #1, once per half: 16 tile columns as rows m, the 16 window rows as
-//             columns n, K = D).  Row m of half `sub` is tile column 8(m>>2) + 4sub + (m&3), so lane (g, i)
-//             ends up holding, for window row i, the scores of tile columns 8g .. 8g+7 - exactly an A
-//             fragment of MFMA #2 (k slot j <-> tile column 8g + j), and row i's edges inside those eight
-//             columns are ONE run of ef.  No data moves between lanes:
-//             Y  += att * Xc    (MFMA #2)
-// The gathered rows land lane-linear in LDS (lane (g, i) DMAs halves 32ks + 8g.. of row m = i of half
-// sub to slot lane*16 of block (sub, ks)); MFMA #1 reads each lane's own slot back, MFMA #2 reads the
-// same bytes through ds_read_b64_tr_b16.  One buffer is
-// enough: every LDS read of tile t completes before the gather of tile t+1 is issued, and that
-// gather is in flight while tile t is multiplied.
-//   forward  (BWD = false): ef = scores (staged per row, flushed as contiguous runs, as in
-//            sddmm_kernel), att = fl32(w * ef), max |ef| recorded for the backward call's scale.
-//   backward (BWD = true):  att = fl32(w * ef_saved) (edge values DMA'd one tile ahead),
-//            scores of dY are only reduced against the column ids: sum_e s[e] * (float)col(e).
-// ------------------------------------------------------------------------------------------
-static constexpr int kAgnnXcds = 8;   // workgroup b runs on XCD b % 8
-struct AgnnArgs {
-    const int64_t* wb_ptr;
-    const int32_t* order;
-    const int32_t* cols;
-    const uint32_t* mask;
-    const int32_t* ebase;
-    const _Float16* x16;
-    const uint32_t* hdr;
-    const float* w;            // attention weight, device scalar
-    float* ef;                 // forward: out [E]; backward: the saved scores (read only)
-    uint32_t* ef_absmax;       // bit pattern of max |ef|: forward accumulates, backward reads
-    float* y;                  // [N, D]
-    double* partial;           // backward: one slot per workgroup
-    int32_t N, Nc, row_off, Dpad, D, stride;
-    int64_t E;
-    const int32_t* rowptr;
-    const uint32_t* bptr;      // range-major walk (MAXW > 0): per-window tile offsets of the column buckets
-    int32_t nbuckets, gsel, nranges, nw, ngroups;
-    int32_t big;               // fp16 image >= 4 GB: 64-bit lane addresses instead of the buffer descriptor
-    int32_t nslices;           // > 0 (MAXW = 0 only): the XCD-sliced walk, see agnn_kernel
-    int32_t valonly;           // backward kernel as an edge-valued SpMM (tcgnn_spmm_val on the sliced walk): Y = sum ef[e] X[col(e)], no scores, w = 1
-};
-
-static constexpr int agnn_wave_lds(int ks, bool bwd) {
-    return 2 * ks * 1024 + kPadBytes + (bwd ? 2048 : 16 * kSddmmStageCap * 4 + 256);   // backward: two 1 KB edge-value blocks
-}
-
-// MAXW = 0: one workgroup per window, each wavefront a contiguous quarter of its tiles.
-// MAXW > 0: persistent wavefronts that own MAXW windows (accumulators in registers) and walk the column
-//           ranges in step, as spmm_blocked_kernel does, so the gathered rows stay L2-resident.
-template <int NT, int WAVES, bool BWD, int MAXW>
-__global__ __launch_bounds__(WAVES * 64, (NT <= 4 ? 3 : 2)) void agnn_kernel(const AgnnArgs a) {
-    const bool valonly = BWD && a.valonly != 0;   // (kernel-uniform)
-    if (valonly ? range_is_wide_val(a.hdr) : wide2_dense(a.hdr)) return;   // (range guard: the fp32 fallback launched behind this kernel does the work; a few dirty rows: wide_patch_kernel)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = (NT + 1) / 2;
-    constexpr int WAVE_LDS = agnn_wave_lds(KS, BWD);
-    constexpr int CAP = kSddmmStageCap;
-    constexpr int NQ = 2 * KS;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, i = lane & 15;
-    const int64_t stride = a.stride;
-    const int kx = scale_exp_from_bits(a.hdr[0]);
-    const bool two_step = kx > 63 || kx < -63;                     // score = acc * 2^(-2kx), in two factors if needed
-    const float inv_a = two_step ? pow2f(-kx) : pow2f(-2 * kx), inv_b = two_step ? pow2f(-kx) : 1.0f;
-    const float wv = a.w ? a.w[0] : 1.0f;
-    // power-of-two scale of the edge weights att = w * ef.  forward: |ef| <= Dpad * max|x|^2 (no pass over E);
-    // backward: the recorded max |ef|.  Rounding to a 10-bit mantissa does not depend on the scale.
-    float att_bound;
-    if constexpr (BWD) att_bound = fabsf(wv) * __uint_as_float(a.ef_absmax[0]);
-    else { const float xm = __uint_as_float(a.hdr[0]); att_bound = fabsf(wv) * (float)a.Dpad * xm * xm; }
-    const int ka = scale_exp_from_bits(__float_as_uint(att_bound));
-    const float c_val = wv * pow2f(ka);   // power-of-two scaling commutes with rounding: fl(x * w) * 2^ka == fl(x * (w * 2^ka))
-    const half8 hz = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x16, (short)(a.stride * 2), a.Nc + 1, 0x00020000);
-    const MetaSource meta(a.cols, a.mask, a.ebase, lane);
-    const uint32_t ring = (uint32_t)(uintptr_t)((LDS_AS char*)(smem + wave * WAVE_LDS));
-    const uint32_t pad = ring + 2 * KS * 1024;
-    const uint32_t aux = pad + kPadBytes;                          // forward: output staging; backward: edge-value pad
-    uint32_t boff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) boff[ks] = (ks * 32 + 8 * g < a.Dpad) ? (uint32_t)(ks * 32 + 8 * g) * 2u : 0u;
-    // pad: cols[32] | mask[16] | ebase[16]; this lane: ids of the tile columns it gathers for the two halves
-    // (row m = i of half sub is tile column 8(i>>2) + 4sub + (i&3)), mask and edge offset of ROW i
-    //
-    // WL (KS = 2, rows of one 128-byte line; r03): WHOLE-LINE gathers.  The layout above makes an instruction take 64 bytes of each
-    // of sixteen rows, so every line is asked for twice, and tools/gather_bench.hip measures what that costs once the rows come out
-    // of L2: 9.2 TB/s at any depth against 14-18 TB/s for instructions that take eight whole rows.  Here instruction q takes the
-    // rows of tile columns 8q .. 8q+7 - lane L the 16-byte chunk of row slot rho = L >> 3 that belongs at position p = L & 7 - into
-    // block q, row-major.  Chunk c of row slot rho lies at position c ^ sw(rho, q), sw = 4 ((rho >> 1) & 1) + sigma(q),
-    // sigma = (0, 2, 3, 1): with it the sixteen lanes of every ds_read_b128 lane group of MFMA #1's operand reads (row i, chunk
-    // 4 ks + g) fall into the sixteen 16-byte bank slots, and so do the eight rows x two chunks a 32-lane group of the transposed
-    // reads of MFMA #2 addresses.  All of it is per-lane constants: the tile loop issues the same instructions as before, plus two
-    // more row ids read from the pad.
-    // KS = 4 (rows of two lines, D = 97 .. 128): the same with four 256-byte rows per instruction, eight instructions, tile column tau in
-    // row slot tau & 3 of block tau >> 2, sw = 8 ((q >> 1) & 1) + 2 rho.  (KS = 3 keeps the layout above: its 192-byte rows are
-    // gathered at a 256-byte pitch, which a row-major image of the tile would have to be sized for.)
-    constexpr bool WL = KS == 2 || KS == 4;
-    constexpr int RB = KS == 2 ? 128 : 256, RPI = 1024 / RB, NI = WL ? 32 / RPI : 2, CPR = RB / 16;   // row bytes, rows per instruction, instructions, chunks per row
-    constexpr int NV = WL ? NI + 2 : 4;                              // words read from the pad per tile: row ids, mask, edge offset
-    auto wl_sw = [](uint32_t rho, uint32_t q) -> uint32_t {
-        if constexpr (KS == 2) return 4u * ((rho >> 1) & 1u) + ((0x1320u >> (4u * q)) & 3u);
-        else return 8u * ((q >> 1) & 1u) + 2u * rho;
-    };
-    auto wl_pos = [&](uint32_t tau, uint32_t c) -> uint32_t {        // byte position of chunk c of tile column tau inside the tile image
-        const uint32_t q = tau / RPI, rho = tau % RPI;
-        return q * 1024u + rho * (uint32_t)RB + ((c ^ wl_sw(rho, q)) * 16u);
-    };
-    const uint32_t pcol = (uint32_t)(8 * (i >> 2) + (i & 3));
-    uint32_t idaddr[NV];
-    if constexpr (WL) {
-#pragma unroll
-        for (int q = 0; q < NI; ++q) idaddr[q] = pad + (uint32_t)(RPI * q + lane / CPR) * 4u;
-    } else { idaddr[0] = pad + pcol * 4u; idaddr[1] = pad + (pcol + 4u) * 4u; }
-    idaddr[NV - 2] = pad + 128u + (uint32_t)i * 4u;
-    idaddr[NV - 1] = pad + 192u + (uint32_t)i * 4u;
-    [[maybe_unused]] uint32_t choff[WL ? NI : 1];                   // WL: byte offset inside the row this lane fetches with instruction q
-    if constexpr (WL) {
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const uint32_t c = (uint32_t)(lane % CPR) ^ wl_sw((uint32_t)(lane / CPR), (uint32_t)q);
-            choff[q] = ((int)(c * 8u) < a.Dpad) ? c * 16u : 0u;      // (a chunk past Dpad: chunk 0 instead - valid memory, multiplied by zeros)
-        }
-    }
-    uint32_t qaddr[NQ];
-#pragma unroll
-    for (int k = 0; k < 2 * KS; ++k) {
-        if constexpr (WL) {   // operand (sub, ks) of MFMA #1: row m = i of half sub (tile column 8 (i >> 2) + 4 sub + (i & 3)), chunk 4 ks + g
-            const uint32_t sub = (uint32_t)(k / KS), ks = (uint32_t)(k % KS);
-            qaddr[k] = ring + wl_pos(8u * (uint32_t)(i >> 2) + 4u * sub + (uint32_t)(i & 3), 4u * ks + (uint32_t)g);
-        } else qaddr[k] = ring + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-    }
-    [[maybe_unused]] const uint32_t vaddr0 = aux + (uint32_t)lane * 16u;   // backward: this lane's run of saved scores (second block: + 1024)
-    const uint32_t caddr[2] = {pad + 32u * (uint32_t)g, pad + 32u * (uint32_t)g + 16u};   // ids of my eight tile columns (backward)
-    // transpose reads: this lane addresses k row j = i >> 2 (row m = 4g + j of half h), feature quad q = i & 3 of slice s
-    uint32_t raddr[NT][2];
-#pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if constexpr (WL) {   // row m = 4g + (i >> 2) of half h = tile column 8g + 4h + (i >> 2); features 16 s + 4 (i & 3) ..
-                raddr[s][h] = ring + wl_pos(8u * (uint32_t)g + 4u * (uint32_t)h + (uint32_t)(i >> 2), 2u * (uint32_t)s + (uint32_t)((i & 3) >> 1)) + 8u * (uint32_t)(i & 1);
-            } else
-                raddr[s][h] = ring + (uint32_t)((h * KS + (s >> 1)) * 1024 + ((2 * (s & 1) + ((i & 3) >> 1)) * 16 + 4 * g + (i >> 2)) * 16 + 8 * (i & 1));
-        }
-    const uint32_t stg_i = aux + (uint32_t)i * CAP * 4u;
-    const uint32_t junk = aux + 16u * CAP * 4u + (uint32_t)lane * 4u;
-    const uint32_t flush_base = aux + (uint32_t)lane * 4u;
-    const uint32_t low8 = (1u << (8 * g)) - 1u;                                         // condensed columns left of my eight
-    const uint32_t halfbits[2] = {0x0f0f0f0fu, 0xf0f0f0f0u};                            // tile columns of each half
-
-    uint32_t emax = 0u;
-    float dsum = 0.f;
-
-    // one run: consecutive tiles t .. te-1 of window w, accumulated into acc
-    auto run = [&](const int w, int64_t t, const int64_t te, floatx4 (&acc)[NT]) {
-        if (t >= te) return;
-        // B operand of MFMA #1: window row i, halves 32*ks + 8g .. +7 (rows past N read the zero sentinel row)
-        int64_t arow = (int64_t)w * kWinRows + i;
-        arow = arow < a.N ? arow + a.row_off : a.Nc;
-        const _Float16* ap = a.x16 + arow * stride + 8 * g;
-        half8 af[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) af[ks] = (ks * 32 + 8 * g < a.Dpad) ? *reinterpret_cast<const half8*>(ap + ks * 32) : hz;
-        const int64_t wrow = (int64_t)w * kWinRows;
-        const int64_t e_w0 = a.rowptr[wrow < a.N ? wrow : a.N];
-        char* const ef_w = reinterpret_cast<char*>(a.ef + e_w0);
-        uint32_t cnt = 0u, rstart = ~0u;                           // staged results of row i / window-relative position of the first
-        [[maybe_unused]] bool flush_pending = false;
-
-        auto flush = [&]() {
-            uint32_t vals[16];
-            lds_rows_block8<CAP * 4, 0>(flush_base, vals);
-            lds_rows_block8<CAP * 4, 8>(flush_base, vals + 8);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t c_r = (uint32_t)__builtin_amdgcn_readlane((int)cnt, r);
-                const uint32_t s_r = (uint32_t)__builtin_amdgcn_readlane((int)rstart, r);
-                if ((uint32_t)lane < c_r) {
-                    st_stream(reinterpret_cast<uint32_t*>(ef_w + ((s_r + (uint32_t)lane) << 2)), vals[r]);
-                    const uint32_t ab = vals[r] & 0x7fffffffu;           // max |ef| for the backward call's scale
-                    emax = ab > emax ? ab : emax;
-                }
-            }
-            cnt = 0u; rstart = ~0u;
-        };
-        auto dma_b = [&](const uint32_t* cid) {
-            if constexpr (WL) {   // NI instructions of RPI whole rows each
-                if (MAXW == 0 && a.big) {
-                    const char* const xb = reinterpret_cast<const char*>(a.x16);
-#pragma unroll
-                    for (int q = 0; q < NI; ++q)
-                        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[q] * (uint64_t)(stride * 2) + choff[q]),
-                                                         (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, 0, 0);
-                    return;
-                }
-#pragma unroll
-                for (int q = 0; q < NI; ++q)
-                    __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + q * 1024), 16, (int)cid[q], (int)choff[q], 0, 0, 0);
-                return;
-            }
-            if (MAXW == 0 && a.big) {   // (the range-major variant, on request only, is at its register limit: the launcher keeps big images off it)
-                const char* const xb = reinterpret_cast<const char*>(a.x16);
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        __builtin_amdgcn_global_load_lds((GLB_AS const void*)(xb + (uint64_t)cid[sub] * (uint64_t)(stride * 2) + boff[ks]),
-                                                         (LDS_AS void*)(uintptr_t)(ring + (sub * KS + ks) * 1024), 16, 0, 0);
-                return;
-            }
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    __builtin_amdgcn_struct_ptr_buffer_load_lds(xrsrc, (LDS_AS void*)(uintptr_t)(ring + (sub * KS + ks) * 1024), 16,
-                                                                (int)cid[sub], (int)boff[ks], 0, 0, 0);
-        };
-        struct Cur { uint32_t m, eb; int sh; bool wide; uintx4 c[2]; };
-        // saved scores of row i inside my eight tile columns: one run of ef.  Four floats (clamped to stay inside ef)
-        // cover it almost always; a second DMA fetches the next four when some lane's run is longer.
-        auto dma_vals = [&](Cur& c) {
-            // (32-bit arithmetic: edge offsets are int32 by the CSR's type)
-            const int32_t e0 = (int32_t)c.eb + __popc(c.m & low8);
-            int32_t lo = min(e0, (int32_t)a.E - 8);
-            lo = max(lo, 0);
-            c.sh = e0 - lo;
-            c.wide = __any(__popc((c.m >> (8 * g)) & 0xffu) + c.sh > 4);
-            __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo), (LDS_AS void*)(uintptr_t)aux, 16, 0, 0);
-            if (c.wide) __builtin_amdgcn_global_load_lds((GLB_AS const void*)(a.ef + lo + 4), (LDS_AS void*)(uintptr_t)(aux + 1024), 16, 0, 0);
-        };
-        auto stage = [&](Cur& cur, int64_t& tcur, int64_t& tn) -> bool {
-            wait_vm0();
-            uint32_t v[NV];
-            uintx4 q[NQ];
-            lds_ids_block<NV>(idaddr, v, qaddr[0], q[0]);         // next tile: its row ids for my lane, my row's mask and edge offset; + operand 0
-            if (!valonly) lds_q_block<NQ - 1, 0>(qaddr + 1, q + 1);   // the other operands (values only: no scores, nothing reads them)
-            // backward: the saved score of tile column j of my eight is word (edges of row i left of it in my run) of the run the
-            // DMA fetched - read by ADDRESS (r03; a cascade of selects over eight registers cost ten VALU instructions per column
-            // in a loop that is VALU-bound: 265 per tile, SQ_INSTS_VALU of profiles/r02).  Lanes without the edge read a
-            // neighbouring word that the mask removes below.
-            [[maybe_unused]] uint32_t sv[8];
-            if constexpr (BWD) {
-                const uint32_t byte0 = (cur.m >> (8 * g)) & 0xffu;
-                uint32_t va = vaddr0 + ((uint32_t)cur.sh << 2), ad[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    ad[j] = va;
-                    va -= (uint32_t)((int32_t)(byte0 << (31 - j)) >> 31) << 2;        // + 4 where the edge exists
-                }
-                if (cur.wide) {   // (wave-uniform, rare: some lane's run crosses into the second block of four)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ad[j] += (((ad[j] - vaddr0) >> 4) & 1u) * 1008u;
-                }
-                lds_read8_b32(ad, sv);
-            }
-            Cur nx;
-            nx.m = v[NV - 2]; nx.eb = v[NV - 1]; nx.sh = 0; nx.wide = false;
-            if constexpr (BWD) lds_q_block<2, 0>(caddr, nx.c);
-            half4 lo[NT], hi[NT];
-            lds_tr_block<NT, 0>(raddr, lo, hi);
-            const bool more = tn < te;
-            const int64_t tnn = tn + 1;
-            if (more) {
-                dma_b(v);
-                if constexpr (BWD) dma_vals(nx);
-                if (tnn < te) meta.dma(tnn, pad);
-            }
-            if constexpr (!BWD) {   // (see sddmm_kernel: a pending flush goes right behind the gather)
-                if (flush_pending) { flush(); flush_pending = false; }
-            }
-            // ---- tile tcur: scores
-            floatx4 S[2];
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                S[sub] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (!valonly && __any((cur.m & halfbits[sub]) != 0u)) {
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        S[sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, q[sub * KS + ks]), af[ks], S[sub], 0, 0, 0);
-                }
-            }
-            // ---- edge weights of row i for my eight tile columns (branch-free; 10-bit RNA rounding done in integer
-            //      arithmetic, after which the round-toward-zero pack conversion is exact)
-            const uint32_t byte = (cur.m >> (8 * g)) & 0xffu;
-            // (the tile loop is VALU-bound - 160 VALU instructions per tile before this form - so the eight columns are
-            // handled with masks instead of compares and selects: mk = all-ones where the edge exists; the second scale
-            // factor is 1.0 unless the exponent needs two steps, and multiplying by it is exact)
-            [[maybe_unused]] uint32_t wpos = stg_i + ((cnt + (uint32_t)__popc(cur.m & low8)) << 2);   // forward: its staging slot
-            uint32_t rb[8];
-            [[maybe_unused]] float scv[8];
-            if constexpr (!BWD) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) scv[j] = S[j >> 2][j & 3] * inv_a;
-                if (__builtin_expect(two_step, 0)) {   // (kernel-uniform, almost never taken; the empty asm keeps it a branch - if-converted
-                                                       //  it costs a multiply and a select per column)
-                    asm volatile("; second scale factor");
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) scv[j] *= inv_b;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);   // (one v_bfe_i32)
-                [[maybe_unused]] const float sraw = S[j >> 2][j & 3];
-                [[maybe_unused]] float sc = 0.f;
-                if constexpr (!BWD) sc = scv[j];
-                float att_s;
-                if constexpr (BWD) {
-                    att_s = __uint_as_float(sv[j]) * c_val;                          // = fl32(w * ef) * 2^ka
-                } else {
-                    lds_write_b32(bitfield_select(mk, wpos, junk), sc);
-                    asm("v_mad_i32_i24 %0, %1, -4, %0" : "+v"(wpos) : "v"(mk));           // wpos += 4 where the edge exists (mk = -1)
-                    att_s = sc * c_val;                                              // = fl32(w * ef) * 2^ka
-                }
-                // (+ half an ulp of the 10-bit mantissa; the 13 bits below it are cut by the round-toward-zero pack conversion itself -
-                //  in fp16's normal range exactly the bits `& 0xffffe000` would clear, below it a coarser cut toward zero of the same value)
-                rb[j] = (__float_as_uint(att_s) & mk) + 0x1000u;
-            }
-            if constexpr (BWD) {
-                if (!valonly) {   // sum_e s[e] * col(e) (the raw accumulators: their power-of-two scale is applied once, to the workgroup's sum)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t mk = (uint32_t)((int32_t)(byte << (31 - j)) >> 31);
-                        dsum += __uint_as_float(__float_as_uint(S[j >> 2][j & 3]) & mk) * (float)(int32_t)cur.c[j >> 2][j & 3];
-                    }
-                }
-            }
-            half8 a16;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const auto pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(rb[j]), __uint_as_float(rb[j + 1]));
-                a16[j] = (_Float16)pk[0];
-                a16[j + 1] = (_Float16)pk[1];
-            }
-            // ---- aggregation
-#pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                const half8 bf = __builtin_shufflevector(lo[s], hi[s], 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16, bf, acc[s], 0, 0, 0);
-            }
-            if constexpr (!BWD) {
-                if (rstart == ~0u && cur.m != 0u) rstart = cur.eb - (uint32_t)e_w0;
-                cnt += (uint32_t)__popc(cur.m);
-                // a tile adds at most 32 results to a row: flush while every row still has room for one more tile
-                if (!more) flush();
-                else flush_pending = __any(cnt > (uint32_t)(CAP - 32));
-            }
-            cur = nx;
-            tcur = tn;
-            tn = tnn;
-            return more;
-        };
-
-        // prologue: metadata of the first tile, its operands [and saved scores], metadata of the second
-        meta.dma(t, pad);
-        wait_vm0();
-        Cur cur;
-        {
-            uint32_t v[NV];
-            uintx4 dummy;
-            lds_ids_block<NV>(idaddr, v, qaddr[0], dummy);
-            cur.m = v[NV - 2]; cur.eb = v[NV - 1]; cur.sh = 0; cur.wide = false;
-            if constexpr (BWD) lds_q_block<2, 0>(caddr, cur.c);
-            dma_b(v);
-            if constexpr (BWD) dma_vals(cur);
-        }
-        int64_t tn = t + 1;
-        if (tn < te) meta.dma(tn, pad);
-        while (stage(cur, t, tn)) {}
-        wait_vm0();
-    };
-
-    const float inv1 = pow2f(-kx), inv2 = pow2f(-ka);
-    auto store_rows = [&](const int w, const int s, const floatx4& v) {
-        const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
-        const int colg = 16 * s + i;
-        if (colg < a.D) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = v[ii] * inv1 * inv2;
-        }
-    };
-
-    [[maybe_unused]] int w0 = 0;
-    [[maybe_unused]] floatx4 acc0[NT];
-    if constexpr (MAXW == 0) {
-#pragma unroll
-        for (int s = 0; s < NT; ++s) acc0[s] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (a.nslices > 0) {
-            // XCD-sliced walk (r03).  Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and here
-            // workgroup b only ever gathers rows of column slice b % nslices: an XCD's 4 MB L2 then holds the one slice of the fp16
-            // image it is asked for (Reddit shape, D = 64: 29.8 MB / 8) instead of seeing all of it - tools/gather_bench.hip: rows out
-            // of an L2-resident slice arrive at 14-17 TB/s against 8.3 TB/s for rows of the whole image, which is what the
-            // per-window walk runs at.  Every wavefront takes the tiles of ONE window inside the slice (bptr: the plan's bucket
-            // table) and stores its sums as that slice's addend of Y (a.y = nslices buffers), which agnn_slice_sum_kernel adds in
-            // slice order: deterministic, and nothing depends on the placement being what is assumed here.
-            // (more than eight slices - an image of 16 .. 32 MB - go in ROUNDS of eight: the grid's first 1 / rounds takes slices
-            //  0 .. 7, the next one slices 8 .. 15, and workgroups start in grid order, so an XCD is asked for one slice at a time)
-            const unsigned per_round = gridDim.x / (unsigned)(a.nslices / kAgnnXcds), b2 = blockIdx.x % per_round;
-            const int slice = (int)(blockIdx.x / per_round) * kAgnnXcds + (int)(b2 % (unsigned)kAgnnXcds);
-            const int wi = (int)(b2 / (unsigned)kAgnnXcds) * WAVES + wave;
-            w0 = wi < a.nw ? __builtin_amdgcn_readfirstlane(a.order[wi]) : -1;
-            if (w0 >= 0) {
-                const int64_t tb = a.wb_ptr[w0];
-                const uint32_t* bp = a.bptr + (int64_t)w0 * (a.nbuckets + 1);
-                run(w0, tb + bp[slice * a.gsel], tb + bp[(slice + 1) * a.gsel], acc0);
-            }
-        } else {
-            w0 = a.order[blockIdx.x];
-            const int64_t tb = a.wb_ptr[w0], te_w = a.wb_ptr[w0 + 1];
-            const int64_t chunk = (te_w - tb + WAVES - 1) / WAVES;         // contiguous share of this wavefront
-            const int64_t t0 = tb + wave * chunk;
-            run(w0, t0, t0 + chunk < te_w ? t0 + chunk : te_w, acc0);
-        }
-    } else {
-        const int gw = blockIdx.x * WAVES + wave, gwn = gridDim.x * WAVES;
-        for (int grp = gw; grp < a.ngroups; grp += gwn) {
-            int wj[MAXW];
-            int64_t tbj[MAXW];
-            floatx4 acc[MAXW][NT];
-#pragma unroll
-            for (int j = 0; j < MAXW; ++j) {
-                const int idx = grp + j * a.ngroups;   // strided picks from the heaviest-first order: balanced groups
-                wj[j] = idx < a.nw ? __builtin_amdgcn_readfirstlane(a.order[idx]) : -1;
-                tbj[j] = wj[j] >= 0 ? a.wb_ptr[wj[j]] : 0;
-#pragma unroll
-                for (int s = 0; s < NT; ++s) acc[j][s] = floatx4{0.f, 0.f, 0.f, 0.f};
-            }
-            for (int r = 0; r < a.nranges; ++r) {
-#pragma unroll
-                for (int j = 0; j < MAXW; ++j) {
-                    if (wj[j] < 0) continue;
-                    const uint32_t* bp = a.bptr + (int64_t)wj[j] * (a.nbuckets + 1);
-                    run(wj[j], tbj[j] + bp[r * a.gsel], tbj[j] + bp[(r + 1) * a.gsel], acc[j]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < MAXW; ++j) {
-                if (wj[j] < 0) continue;
-#pragma unroll
-                for (int s = 0; s < NT; ++s) store_rows(wj[j], s, acc[j][s]);
-            }
-        }
-    }
-
-    if constexpr (BWD) {
-        // sum_e score(e) * col(e): per-wavefront double, then one slot per workgroup (fixed order -> deterministic)
-        double d = (double)dsum * (double)inv_a * (double)inv_b;   // (dsum holds raw MFMA sums: scores * 2^(2 kx))
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-        __syncthreads();
-        double* dred = reinterpret_cast<double*>(smem);
-        if (lane == 0) dred[wave] = d;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-            for (int ww = 0; ww < WAVES; ++ww) tot += dred[ww];
-            a.partial[blockIdx.x] = tot;
-        }
-    } else {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)emax, off, 64); emax = o > emax ? o : emax; }
-        // one word for the whole launch: 600k same-address atomics serialise in one L2 channel (12 ns each - they cost
-        // 3 ms on the ogbn-products shape).  The running maximum stops growing after a handful of wavefronts, so look first.
-        if (lane == 0 && emax != 0u && emax > __hip_atomic_load(a.ef_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(a.ef_absmax, emax);
-    }
-
-    // ---- per-window workgroups: combine the wavefronts' partial sums in a fixed order and store
-    if constexpr (MAXW == 0) {
-        if (a.nslices > 0) {   // a wavefront = a window: its sums are one slice's addend
-            if (w0 >= 0) {
-                const unsigned per_round = gridDim.x / (unsigned)(a.nslices / kAgnnXcds);
-                const int slice = (int)(blockIdx.x / per_round) * kAgnnXcds + (int)((blockIdx.x % per_round) % (unsigned)kAgnnXcds);
-                const int64_t row0 = (int64_t)w0 * kWinRows + 4 * g;
-                float* const yp = a.y + (int64_t)slice * a.N * a.D;
-#pragma unroll
-                for (int s = 0; s < NT; ++s) {
-                    const int colg = 16 * s + i;
-                    if (colg < a.D) {
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii)
-                            if (row0 + ii < a.N) st_stream(&yp[(row0 + ii) * a.D + colg], acc0[s][ii] * inv1 * inv2);
-                    }
-                }
-            }
-        } else if constexpr (WAVES > 1) {
-            __syncthreads(); // every wave is done with its LDS
-            floatx4* red = reinterpret_cast<floatx4*>(smem);
-#pragma unroll
-            for (int s = 0; s < NT; ++s) red[(wave * NT + s) * 64 + lane] = acc0[s];
-            __syncthreads();
-            for (int s = wave; s < NT; s += WAVES) {
-                floatx4 v = red[s * 64 + lane];
-#pragma unroll
-                for (int ww = 1; ww < WAVES; ++ww) {
-                    const floatx4 o = red[(ww * NT + s) * 64 + lane];
-                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-                }
-                store_rows(w0, s, v);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < NT; ++s) store_rows(w0, s, acc0[s]);
-        }
-    }
-}
-
-// Y = sum of the XCD-sliced walk's addends, in slice order (float4 where the pointers allow)
-__global__ __launch_bounds__(256) void agnn_slice_sum_kernel(const float* __restrict__ part, float* __restrict__ y, int64_t n, int64_t stride, int32_t nslices) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
-    if (((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && ((n | stride) & 3) == 0) {
-        const int64_t n4 = n >> 2, s4 = stride >> 2;
-        const float4* p4 = reinterpret_cast<const float4*>(part);
-        for (int64_t k = gid; k < n4; k += gsz) {
-            float4 v = p4[k];
-            for (int s = 1; s < nslices; ++s) { const float4 o = p4[(int64_t)s * s4 + k]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            reinterpret_cast<float4*>(y)[k] = v;
-        }
-    } else {
-        for (int64_t k = gid; k < n; k += gsz) {
-            float v = part[k];
-            for (int s = 1; s < nslices; ++s) v += part[(int64_t)s * stride + k];
-            y[k] = v;
-        }
-    }
-}
-
-// partial[0..n) -> out[0], fixed order.  One workgroup of 1024, four independent loads per thread and step: the sliced walk leaves
-// 29 k partials on the Reddit shape, and 256 threads taking one dependent load per step spent 47 us on them (a memory round trip
-// per step) - 2 x 47 us of an AGNN epoch.
-static constexpr int kReduceThreads = 1024;
-__global__ __launch_bounds__(kReduceThreads) void agnn_reduce_kernel(const double* __restrict__ partial, int32_t n, float* __restrict__ out, const double* __restrict__ extra = nullptr) {
-    __shared__ double sh[kReduceThreads];
-    double s = 0.0;
-    int k = (int)threadIdx.x;
-    for (; k + 3 * kReduceThreads < n; k += 4 * kReduceThreads) {
-        const double a = partial[k], b = partial[k + kReduceThreads], c = partial[k + 2 * kReduceThreads], d = partial[k + 3 * kReduceThreads];
-        s += (a + b) + (c + d);
-    }
-    for (; k < n; k += kReduceThreads) s += partial[k];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = kReduceThreads / 2; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (float)(sh[0] + (extra ? extra[0] : 0.0));   // (extra: wide_patch_kernel's correction, header words 10-11; zero unless the call was patched)
-}
-
-// ------------------------------------------------------------------------------------------
-// Small graphs: SpMM in ONE launch (binary A).
-// Citeseer / Cora / Pubmed-sized inputs are launch-latency work (reference: 0.040 ms per call on an RTX 3090,
-// logs/profile.csv:2): the fp16 path costs a memset + absmax + convert + the kernel.  Here one wavefront per window reads
-// fp32 X directly, rounds each operand to a 10-bit mantissa like the reference's TF32 conversion (round_rna10: no range
-// limit, so no scale pass) and multiplies on the fp32 matrix pipe: v_mfma_f32_16x16x4_f32, A = 16 rows x 4 condensed
-// columns of the adjacency mask as 0.0 / 1.0, B = the 4 gathered rows x 16 feature columns.  1/16 of the fp16 MFMA rate,
-// irrelevant at this size.  Accumulation in tile order, fp32, like the other kernels.
-// ------------------------------------------------------------------------------------------
-struct SpmmSmallArgs {
-    const int64_t* wb_ptr;
-    const int32_t* cols;
-    const uint32_t* mask;
-    const float* x;
-    const float* gate;   // optional: operand element (r, c) counts only where gate[r, c] > 0 (ReLU backward mask)
-    float* y;
-    int32_t N, Nc, D, relu;
-    const uint32_t* guard;   // nullptr: the kernel of small graphs.  Else the header of a staged image: this launch is the range guard's
-                             // fallback behind an fp16-path kernel and returns at once unless that matrix is "wide" (range_is_wide)
-};
-typedef float floatx4s __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void spmm_small_kernel(const SpmmSmallArgs a) {
-    if (a.guard && !range_is_wide(a.guard, 0)) return;
-    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
-    const int w = blockIdx.x;
-    const int coloff = (int)blockIdx.y * 64;
-    floatx4s acc[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s] = floatx4s{0.f, 0.f, 0.f, 0.f};
-    const int64_t tb = a.wb_ptr[w], te = a.wb_ptr[w + 1];
-    for (int64_t t = tb; t < te; ++t) {
-        const uint32_t m = a.mask[t * kWinRows + i];
-        int32_t id[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) id[j] = a.cols[t * kWbCols + 4 * j + g];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float av = ((m >> (4 * j + g)) & 1u) ? 1.0f : 0.0f;
-            const int64_t roff = (int64_t)id[j] * a.D + coloff + i;
-            const float* row = a.x + roff;
-            const bool live = id[j] < a.Nc;   // Nc = "no column": the zero sentinel of the packed stream
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float bv = (live && coloff + 16 * s + i < a.D) ? round_rna10(row[16 * s]) : 0.0f;
-                if (a.gate && live && coloff + 16 * s + i < a.D && !(a.gate[roff + 16 * s] > 0.0f)) bv = 0.0f;
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[s], 0, 0, 0);
-            }
-        }
-    }
-    const int64_t row0 = (int64_t)w * kWinRows + 4 * g;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int colg = coloff + 16 * s + i;
-        if (colg < a.D) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-                if (row0 + ii < a.N) a.y[(row0 + ii) * a.D + colg] = relu_if(a.relu, acc[s][ii]);
-        }
-    }
-}
-static constexpr int64_t kSmallMaxTiles = 8192;   // wide blocks up to which the single-launch kernel is used (mode 0)
-
-// ------------------------------------------------------------------------------------------
-// fallbacks for non-canonical CSR rows (unsorted or duplicated column ids)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spmm_val_csr_kernel(const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col,
-                                                           const float* __restrict__ val,
-                                                           const float* __restrict__ X, float* Y,
-                                                           int32_t N, int32_t D) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int d = lane; d < D; d += 64) {
-        float s = 0.f;
-        for (int64_t e = e0; e < e1; ++e) s += round_rna10(val[e]) * round_rna10(X[(int64_t)col[e] * D + d]);
-        Y[row * D + d] = s;
-    }
-}
-
-__global__ __launch_bounds__(256) void sddmm_csr_kernel(const int32_t* __restrict__ rowptr,
-                                                        const int32_t* __restrict__ col,
-                                                        const float* __restrict__ X, float* ef,
-                                                        int32_t N, int32_t D, int32_t row_off) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const int lane = threadIdx.x & 63;
-    const float* xr = X + (row + row_off) * D;
-    for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
-        const float* xc = X + (int64_t)col[e] * D;
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) ef[e] = s;
-    }
-}
-
-// ---- fallbacks behind the range guard (range_is_wide): launched behind every fp16-path kernel, they return at once unless the
-//      staged matrix is "wide".  Plain fp32, CSR order, operands rounded to a 10-bit mantissa exactly like the reference's
-//      (round_rna10) with fp32's full exponent: correct for any magnitudes, far from fast - a wide matrix is a rare input.
-// Y[row] = [relu] sum_e v_e * rna(X'[col e]) with v_e = 1 (binary), rna(val[e]) or rna(fl32(w * val[e])) (the AGNN edge weights);
-// X' = X where gate > 0 (the fused ReLU backward mask).  ldx / ldy: row strides (column blocks of wider matrices).
-__global__ __launch_bounds__(256) void spmm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, int use_val_word, const int32_t* __restrict__ rowptr,
-                                                                 const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ wscale,
-                                                                 const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int32_t N, int32_t D,
-                                                                 int64_t ldx, int64_t ldy, int32_t relu, int32_t dedupe) {
-    if (!(use_val_word ? range_is_wide_val(hdr) : range_is_wide(hdr, 0))) return;
-    const int lane = threadIdx.x & 63;
-    const float w = wscale ? wscale[0] : 1.0f;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < N; row += (int64_t)gridDim.x * 4) {   // (a small grid: the usual launch returns above)
-    const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int d = lane; d < D; d += 64) {
-        float s = 0.f;
-        for (int64_t e = e0; e < e1; ++e) {
-            if (dedupe) {   // binary A on a non-canonical row: an edge listed twice counts once (TCGNN_kernel.cu:405)
-                bool dup = false;
-                for (int64_t e2 = e0; e2 < e; ++e2) dup = dup || col[e2] == col[e];
-                if (dup) continue;
-            }
-            const int64_t xi = (int64_t)col[e] * ldx + d;
-            float x = X[xi];
-            if (gate && !(gate[xi] > 0.0f)) x = 0.0f;
-            const float v = val ? round_rna10(wscale ? w * val[e] : val[e]) : 1.0f;
-            s += v * round_rna10(x);
-        }
-        Y[row * ldy + d] = relu_if(relu, s);
-    }
-    }
-}
-// Y[row] = [relu] ((A X)[row]) W: the aggregated row goes through LDS, then every lane takes output columns (D_in, D_out <= 128)
-__global__ __launch_bounds__(256) void spmm_gemm_wide_fallback_kernel(const uint32_t* __restrict__ hdr, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                                      const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Y, int32_t N,
-                                                                      int32_t Din, int32_t Dout, int32_t relu) {
-    if (!range_is_wide(hdr, 0)) return;
-    __shared__ float agg[4][128];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t row0 = (int64_t)blockIdx.x * 4; row0 < N; row0 += (int64_t)gridDim.x * 4) {
-    const int64_t row = row0 + wv;
-    __syncthreads();
-    if (row < N) {
-        const int64_t e0 = rowptr[row], e1 = rowptr[row + 1];
-        for (int d = lane; d < Din; d += 64) {
-            float s = 0.f;
-            for (int64_t e = e0; e < e1; ++e) s += round_rna10(X[(int64_t)col[e] * Din + d]);
-            agg[wv][d] = s;
-        }
-    }
-    __syncthreads();
-    if (row < N)
-    for (int o = lane; o < Dout; o += 64) {
-        float s = 0.f;
-        for (int k = 0; k < Din; ++k) s = fmaf(agg[wv][k], W[(int64_t)k * Dout + o], s);
-        Y[row * Dout + o] = relu_if(relu, s);
-    }
-    }
-}
-// ---- the sparse way through a wide matrix (see wide2_sparse): every edge (r, c) whose row of X or whose column's row of X is dirty
-//      is recomputed in fp32 with the reference's operand rounding.
-//   mode 0 (SDDMM):          ef[e] = <rna(x_r), rna(x_c)>
-//   mode 1 (fused forward):  the same, max |ef| kept up to date, and Y[r] += rna(w ef_new) rna(x_c) - rna(w ef_old) img(x_c): the
-//                            edge's contribution as the reference computes it minus what the MFMA kernel added (img = the fp16 image)
-//   mode 2 (fused backward): X = dY, ef = the saved scores: G[r] += rna(w ef) (rna(x_c) - img(x_c)) and the edge's term of d_w,
-//                            (<rna(x_r), rna(x_c)> - <img(x_r), img(x_c)>) col(e), into one extra double behind the partial sums
-// Workgroups 0 .. kSparseRows - 1 take the edges OF dirty row b (a wavefront's lane = an edge); the others scan the column index
-// for edges INTO a dirty row whose own row is clean.  Atomic adds: the order of the corrections of one row is not fixed - in a path
-// that exists for a handful of rows per call.
-struct PatchArgs {
-    const uint32_t* hdr;
-    const int32_t* rowptr; const int32_t* col; const int32_t* e2r;
-    const float* X; const _Float16* x16; int32_t pitch;
-    float* ef; const float* w; float* Y; uint32_t* efmax; double* dw_extra;
-    int32_t N, Nc, D, row_off, mode; int64_t E;
-};
-__device__ __forceinline__ void patch_edge(const PatchArgs& a, int64_t e, int64_t r, int32_t c, bool c_dirty) {
-    const float* xr = a.X + (r + a.row_off) * a.D;
-    const float* xc = a.X + (int64_t)c * a.D;
-    const _Float16* ir = a.x16 + (r + a.row_off) * a.pitch;
-    const _Float16* ic = a.x16 + (int64_t)c * a.pitch;
-    const float inv = pow2f(-scale_exp_from_bits(a.hdr[0]));
-    float exact = 0.f, dimg = 0.f;
-    for (int d = 0; d < a.D; ++d) { exact += round_rna10(xr[d]) * round_rna10(xc[d]); dimg += ((float)ir[d] * inv) * ((float)ic[d] * inv); }
-    if (a.mode == 0) { a.ef[e] = exact; return; }
-    const float w = a.w[0];
-    if (a.mode == 1) {
-        const float a_old = round_rna10(w * a.ef[e]), a_new = round_rna10(w * exact);
-        a.ef[e] = exact;
-        atomicMax(a.efmax, __float_as_uint(exact) & 0x7fffffffu);
-        for (int d = 0; d < a.D; ++d) atomicAdd(&a.Y[r * a.D + d], a_new * round_rna10(xc[d]) - a_old * ((float)ic[d] * inv));
-        return;
-    }
-    const float att = round_rna10(w * a.ef[e]);
-    if (c_dirty)
-        for (int d = 0; d < a.D; ++d) atomicAdd(&a.Y[r * a.D + d], att * (round_rna10(xc[d]) - (float)ic[d] * inv));
-    atomicAdd(a.dw_extra, ((double)exact - (double)dimg) * (double)(float)c);
-}
-// the dense way through a wide matrix, inside the same launch (more than kSparseRows dirty rows: the MFMA kernel returned at once):
-// plain fp32 in CSR order with the reference's operand rounding (as spmm_wide_fallback_kernel), a wavefront per row - every row's
-// scores, then its aggregate from them, then (backward) its share of d_w into this workgroup's partial sum.
-__device__ __forceinline__ void wide_dense_body(const PatchArgs& a, double* partial, int32_t npartial) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = a.mode == 2 ? (int)min((uint32_t)gridDim.x, (uint32_t)npartial) : (int)gridDim.x;
-    __shared__ double wsum[4];
-    double acc = 0.0;
-    uint32_t m = 0u;
-    const float w = a.w ? a.w[0] : 1.0f;
-    if ((int)blockIdx.x < nb)
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.N; row += (int64_t)nb * 4) {
-        const float* xr = a.X + (row + a.row_off) * a.D;
-        const int64_t e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-        if (a.mode != 2 || a.dw_extra)
-            for (int64_t e = e0; e < e1; ++e) {
-                const float* xc = a.X + (int64_t)a.col[e] * a.D;
-                float s = 0.f;
-                for (int d = lane; d < a.D; d += 64) s += round_rna10(xr[d]) * round_rna10(xc[d]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (a.mode == 2) acc += (double)s * (double)(float)a.col[e];
-                else if (lane == 0) { a.ef[e] = s; m = max(m, __float_as_uint(s) & 0x7fffffffu); }
-            }
-        if (a.mode == 0) continue;
-        __threadfence_block();            // (mode 1: this wavefront reads back the scores its lane 0 has just written)
-        for (int d = lane; d < a.D; d += 64) {
-            float s = 0.f;
-            for (int64_t e = e0; e < e1; ++e) s += round_rna10(w * a.ef[e]) * round_rna10(a.X[(int64_t)a.col[e] * a.D + d]);
-            a.Y[row * a.D + d] = s;
-        }
-    }
-    if (a.mode == 1 && a.efmax && lane == 0 && m) atomicMax(a.efmax, m);
-    if (a.mode == 2) {
-        if (lane == 0) wsum[wave] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int k = (int)blockIdx.x; k < npartial; k += (int)gridDim.x) partial[k] = (k == (int)blockIdx.x && (int)blockIdx.x < nb) ? (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]) : 0.0;
-    }
-}
-__global__ __launch_bounds__(256) void wide_patch_kernel(const PatchArgs a, double* partial, int32_t npartial) {
-    if (!range_is_wide(a.hdr, 0)) return;
-    if (a.hdr[8] > kSparseRows) { wide_dense_body(a, partial, npartial); return; }
-    __shared__ int32_t dirty[kSparseRows];
-    __shared__ int32_t ndirty;
-    if (threadIdx.x == 0) {   // the list without duplicates, sorted (48 entries: insertion sort)
-        const int n = (int)min(a.hdr[8], kSparseRows);
-        int m = 0;
-        for (int k = 0; k < n; ++k) {
-            const int32_t v = (int32_t)a.hdr[16 + k];
-            int j = 0;
-            while (j < m && dirty[j] < v) ++j;
-            if (j < m && dirty[j] == v) continue;
-            for (int q = m; q > j; --q) dirty[q] = dirty[q - 1];
-            dirty[j] = v; ++m;
-        }
-        ndirty = m;
-    }
-    __syncthreads();
-    const int nd = ndirty;
-    auto is_dirty = [&](int32_t x) { int lo = 0, hi = nd; while (lo < hi) { const int mid = (lo + hi) >> 1; if (dirty[mid] < x) lo = mid + 1; else hi = mid; } return lo < nd && dirty[lo] == x; };
-    if (blockIdx.x < kSparseRows) {
-        if ((int)blockIdx.x >= nd) return;
-        const int64_t r = (int64_t)dirty[blockIdx.x] - a.row_off;       // the row of A this row of X belongs to
-        if (r < 0 || r >= a.N) return;
-        for (int64_t e = a.rowptr[r] + threadIdx.x; e < a.rowptr[r + 1]; e += blockDim.x) patch_edge(a, e, r, a.col[e], is_dirty(a.col[e]));
-        return;
-    }
-    const int64_t first = (int64_t)(blockIdx.x - kSparseRows) * blockDim.x + threadIdx.x, step = (int64_t)(gridDim.x - kSparseRows) * blockDim.x;
-    const int32_t lo_id = nd ? dirty[0] : 0, hi_id = nd ? dirty[nd - 1] : -1;
-    for (int64_t e = first; e < a.E; e += step) {
-        const int32_t c = a.col[e];
-        if (c < lo_id || c > hi_id || !is_dirty(c)) continue;
-        const int64_t r = a.e2r[e];
-        if (r < 0 || r >= a.N || is_dirty((int32_t)(r + a.row_off))) continue;      // (its own row is dirty: the row's workgroup patches it)
-        patch_edge(a, e, r, c, true);
-    }
-}
-static hipError_t launch_wide_patch(const PatchArgs& a, hipStream_t stream, double* partial = nullptr, int32_t npartial = 0) {
-    hipLaunchKernelGGL(wide_patch_kernel, dim3(kSparseRows + 1024), dim3(256), 0, stream, a, partial, npartial);
-    return hipGetLastError();
-}
+#include "tcgnn_small_fallback.inc"
 
 // ------------------------------------------------------------------------------------------
 // launch tables
@@ -2326,10 +404,22 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
     return hipGetLastError();
 }
 
-static int g_bucket_min_tiles = [] { const char* e = getenv("TCGNN_BUCKET_MIN_TILES"); return e ? atoi(e) : 2; }();   // tiles per (window, bucket) a bucket table needs
-static int g_lds_auto = [] { const char* e = getenv("TCGNN_LDS_AUTO"); return e ? atoi(e) : 1; }();
+// ---- run-time switches.  Product: TCGNN_SPMM_MODE / TCGNN_RANGE_GUARD (initial values of tcgnn_set_spmm_mode / tcgnn_set_range_guard,
+// include/tcgnn.h) and TCGNN_VERBOSE (plan statistics on stderr).  TEST AIDS, read through test_knob() only - tests/ forces every walk
+// and layout through them against the oracle; no caller needs them: TCGNN_LDS_AUTO=0 (automatic mode never takes the LDS-resident
+// kernel), TCGNN_LDS_MAXW=4|8 (one layout for every pass), TCGNN_LDS_FLAT=0|1|2 (ordinary stream / tiles per cell),
+// TCGNN_LDS_HOT_COLS (hot / cold threshold), TCGNN_LDS_PLACE=local|localsplit|global, TCGNN_AGNN_SLICED=0|1|2|16,
+// TCGNN_SDDMM_XCD=0|1|2, TCGNN_RANGE_KB (column-range size of the range-major walks).  The A/B switches of closed experiments (r01-r03: DESIGN.md lists what each measured) are gone; the
+// phase timers of the LDS-resident kernels (TCGNN_LDS_DBG) exist only in a -DTCGNN_DEBUG_TIMERS build (make DEBUG_TIMERS=1).
+static const char* test_knob(const char* name) { return getenv(name); }
+static constexpr int g_bucket_min_tiles = 2;   // tiles per (window, bucket) a bucket table needs
+static int g_lds_auto = [] { const char* e = test_knob("TCGNN_LDS_AUTO"); return e ? atoi(e) : 1; }();
+#ifdef TCGNN_DEBUG_TIMERS
 static int g_lds_dbg = [] { const char* e = getenv("TCGNN_LDS_DBG"); return e ? atoi(e) : 0; }();
-static int g_lds_fill_quota = [] { const char* e = getenv("TCGNN_LDS_FILL_QUOTA"); return e ? atoi(e) : 1; }();   // A/B aid (tcgnn_lds_flat.inc)
+#else
+static constexpr int g_lds_dbg = 0;
+#endif
+static constexpr int g_lds_fill_quota = 1;     // (r03: the wavefronts with an empty last slot take the range fills, -0.5 %)
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
@@ -2405,7 +495,7 @@ static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
 enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
 static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_out) {
     *nslices_out = 0;
-    const char* const env = getenv("TCGNN_AGNN_SLICED");
+    const char* const env = test_knob("TCGNN_AGNN_SLICED");
     const int knob = env ? atoi(env) : 1;
     if (!knob || plan->waves != 4 || plan->nbuckets < 8 || plan->nw_eff < 1 || plan->nbuckets % kAgnnXcds) return kAgnnPerWindow;
     const int pitch = x16_pitch(round_up(D, 16));
@@ -2497,786 +587,7 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     return TCGNN_OK;
 }
 
-// Cell stream of the LDS-resident column-range SpMM: per (workgroup, range, wavefront, window slot) the window's
-// condensed columns inside the range, re-tiled 32 to a tile.  Built from the packed tile stream (cols / mask).
-static int g_lds_maxw = [] { const char* e = getenv("TCGNN_LDS_MAXW"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();   // 0: by width
-// Passes of the LDS-resident kernel over a matrix of dpad columns.  Whole 64-column chunks go as two 32-column passes of the
-// 8-windows-per-wavefront layout (half the workgroups stream each plane pair, 760-row ranges: Reddit D = 64 0.56 vs 0.79 ms),
-// what is left over (1-3 planes) as one pass of the 4-window layout.  TCGNN_LDS_MAXW = 4 / 8 forces one layout for every
-// pass (tests, timing).
-struct LdsPass { int maxw, nt, chunk0, nchunks; };
-static int lds_passes(int dpad, LdsPass (&passes)[2]) {
-    int n = 0;
-    if (g_lds_maxw) {
-        const int cd = lds_chunk_dims(g_lds_maxw);
-        if (dpad / cd) passes[n++] = {g_lds_maxw, cd / 16, 0, dpad / cd};
-        if (dpad % cd) passes[n++] = {g_lds_maxw, (dpad % cd) / 16, dpad / cd, 1};
-    } else {
-        // (r03: a remainder of THREE planes - Reddit's 41 classes - goes as one more pair of 32-column chunks of the 8-window layout,
-        //  the fourth plane lying beyond the matrix and filled with zeros: 0.45 ms against 0.51 for the 3-plane pass of the 4-window
-        //  layout, which streams 22 MB per CU and has no room for the in-kernel cold remainder)
-        const int full = dpad / 64, rem = (dpad % 64) / 16;
-        if (full || rem == 3) passes[n++] = {kLdsMaxW2, 2, 0, 2 * (full + (rem == 3 ? 1 : 0))};
-        if (rem && rem != 3) passes[n++] = {kLdsMaxW, rem, full, 1};
-    }
-    return n;
-}
-// workgroups of one pass: enough to hold every window, spread over every CU a pass can have (with 8 windows per wavefront a
-// 64-column chunk takes two passes, hence half the CUs each)
-static bool lds_has_hubs(const tcgnn_plan* p) {
-    int64_t mx = 0;
-    for (int w = 0; w < p->nw_eff; ++w) mx = std::max<int64_t>(mx, p->h_bp[(size_t)w]);
-    return mx * p->nw_eff > 4 * std::max<int64_t>(p->tc_blocks, 1);
-}
-// Placements of a cell stream (lds_place_windows): contiguous weight-balanced blocks per workgroup (locality: the hot / cold split,
-// wavefronts of a workgroup busy in the same ranges), the same with hub windows split, or longest-first over the whole graph with
-// hub windows split.  Graphs without hubs take the first; graphs with hubs build the count tables of the other two and keep the
-// one whose estimated time is lower (build_lds_cells).  TCGNN_LDS_PLACE=local|localsplit|global forces one.
-enum { kPlaceLocal = 0, kPlaceLocalSplit = 1, kPlaceGlobal = 2 };
-static int lds_place_forced() {
-    const char* env = getenv("TCGNN_LDS_PLACE");
-    if (!env) return -1;
-    return !strcmp(env, "global") ? kPlaceGlobal : (!strcmp(env, "localsplit") ? kPlaceLocalSplit : kPlaceLocal);
-}
-static int lds_buf_rows_for_maxw(int maxw) { return maxw == kLdsMaxW2 ? 768 : 512; }   // (the shortest ranges of the layout: the finest spread)
-// weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
-// ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
-static double lds_window_weight(const tcgnn_plan* p, int w, double nranges_d) {
-    const double cols = 8.0 * std::max(p->h_bp[(size_t)w], 1);
-    return std::ceil(cols / 32.0 + nranges_d * (1.0 - std::exp(-cols / nranges_d)));
-}
-static int lds_workgroups_unsplit(const tcgnn_plan* p, int maxw, int extra_slots) {
-    const int per_wg = kLdsWaves * maxw;
-    const int64_t slots = (int64_t)p->nw_eff + extra_slots;
-    int nwg = (int)((slots + per_wg - 1) / per_wg);
-    const int cu_target = maxw == kLdsMaxW2 ? std::max(1, p->num_cus / 2) : p->num_cus;
-    if (nwg < cu_target) nwg = std::max(nwg, std::min(cu_target, (p->nw_eff + kLdsWaves - 1) / kLdsWaves));
-    return nwg;
-}
-// Hub windows: a wavefront owns whole windows, so a window whose tiles exceed a wavefront's fair share of the workgroup's work
-// is the critical path of every range (R-MAT, Reddit shape: the window of the sixteen top hubs holds 3.6 wavefront shares).
-// Such a window is SPLIT: k wavefronts of one workgroup each take every k-th run of its tiles in every range and their partial
-// sums are added through LDS, in a fixed order, at the end of the kernel.  parts[w] = k (1: whole).  Only on graphs that take the
-// graphs with hubs (lds_has_hubs); TCGNN_LDS_SPLIT=0 switches it off.
-static constexpr int kLdsMaxParts = 8, kLdsMaxFollowers = 32;   // (followers of a workgroup: 32 x NT KB of LDS scratch)
-static int lds_split_parts(const tcgnn_plan* p, int maxw, std::vector<uint8_t>* parts, const std::vector<double>* exact = nullptr) {
-    static const int enabled = [] { const char* e = getenv("TCGNN_LDS_SPLIT"); return e ? atoi(e) : 1; }();
-    const int nw = p->nw_eff;
-    if (parts) parts->assign((size_t)nw, 1);
-    if (!enabled || nw <= 0 || !lds_has_hubs(p)) return 0;
-    const double nranges_d = std::max(1.0, std::ceil((double)p->Nc / (lds_buf_rows_for_maxw(maxw) - 8)));
-    auto weight = [&](int w) { return exact ? (*exact)[(size_t)w] : lds_window_weight(p, w, nranges_d); };
-    double total = 0;
-    for (int w = 0; w < nw; ++w) total += weight(w);
-    const double share = total / ((double)lds_workgroups_unsplit(p, maxw, 0) * kLdsWaves);
-    int extra = 0;
-    for (int w = 0; w < nw; ++w) {
-        const double wt = weight(w);
-        if (wt <= 1.5 * share) continue;
-        const int k = (int)std::min<double>(kLdsMaxParts, std::ceil(wt / share));
-        if (k < 2) continue;
-        if (parts) (*parts)[(size_t)w] = (uint8_t)k;
-        extra += k - 1;
-    }
-    return extra;
-}
-static int lds_workgroups(const tcgnn_plan* p, int maxw) {
-    const int which = maxw == kLdsMaxW2 ? 1 : 0;
-    int extra = p->lds_extra[which].load(std::memory_order_relaxed);
-    if (extra < 0) { extra = lds_split_parts(p, maxw, nullptr); p->lds_extra[which].store(extra, std::memory_order_relaxed); }
-    return lds_workgroups_unsplit(p, maxw, extra);
-}
-
-// Kernel-time models behind the automatic choice between the LDS-resident kernel and the gather walks, microseconds on
-// MI355X (tools/check_lds_threshold.py: nine graphs x two widths; the estimates land within ~15 % of the measured times).
-// The LDS kernel's time follows the column ranges it walks, almost whatever the edge count: per range a fixed part (barrier,
-// DMA issue, metadata; grows with the bytes a range streams) plus ~0.135 us per tile a wavefront multiplies; workgroups
-// beyond one per CU run in further rounds.  The gather walks' time follows the edge count.
-static double lds_estimate_us(const tcgnn_plan* p, int dpad) {
-    LdsPass passes[2];
-    const int np = lds_passes(dpad, passes);
-    const double cols_per_window = 32.0 * (double)p->total_wb / std::max(p->nw_eff, 1);
-    double t = 25.0;
-    for (int i = 0; i < np; ++i) {
-        const int maxw = passes[i].maxw, nt = passes[i].nt;
-        const int rows = lds_stream_buf_rows(lds_stream_of(nt, maxw)) - 8;
-        const double nranges = std::ceil((double)p->Nc / rows);
-        const int nwg = lds_workgroups(p, maxw);
-        const double rounds = std::ceil((double)nwg * passes[i].nchunks / std::max(p->num_cus, 1));
-        const double c = cols_per_window / nranges;                                   // distinct columns of a cell
-        const double tiles_per_cell = c <= 24.0 ? 1.0 - std::exp(-c) : c / 32.0 + 0.5;
-        const double windows_per_wave = (double)p->nw_eff / ((double)nwg * kLdsWaves);
-        static const double fixed4[4] = {0.47, 0.60, 0.89, 1.16};
-        const double a = maxw == kLdsMaxW2 ? 0.80 : fixed4[std::min(nt, 4) - 1];
-        t += rounds * nranges * (a + 0.135 * windows_per_wave * tiles_per_cell);
-    }
-    return t;
-}
-static double gather_estimate_us(const tcgnn_plan* p, int dpad) {
-    const double image = ((double)p->Nc + 1) * x16_pitch(dpad) * 2.0;
-    double ps;   // picoseconds per edge
-    if (image <= (double)kBlockedMinBytes) ps = 4.6 + std::max(0, dpad - 16) * (1.8 / 48.0);        // L2-resident image, per-window walk
-    else if (dpad <= 32) ps = 8.5;
-    else if (dpad <= 64) ps = 8.5 + (dpad - 32) * (1.1 / 32.0);
-    else ps = 9.6 + (dpad - 64) * (6.9 / 64.0);
-    // the gathered image leaves first the L2s, then the Infinity Cache (row shards of the multi-GPU workload: 60 / 119 / 239 MB
-    // -> 10.0 / 12.4 / 14.7 ps per edge at 64 columns)
-    if (image > 45.0e6) ps *= std::pow(image / 45.0e6, 0.3);
-    return 20.0 + (double)p->E * ps * 1e-6;
-}
-// automatic mode: the LDS-resident kernel when its estimate is clearly the lower one (decided once per plan and width)
-static bool lds_chosen(const tcgnn_plan* p, int dpad) {
-    if (!g_lds_auto || p->nw_eff <= 0 || p->total_wb <= 0) return false;
-    const int k = dpad / 16;
-    if (k <= 64 && p->lds_choice[k] >= 0) return p->lds_choice[k] != 0;
-    LdsPass passes[2];
-    const int np = lds_passes(dpad, passes);
-    double cells = 0;   // cell-table entries of the streams this width needs (host scan + device memory)
-    for (int i = 0; i < np; ++i) {
-        const int rows = lds_stream_buf_rows(lds_stream_of(passes[i].nt, passes[i].maxw)) - 8;
-        cells += (double)lds_workgroups(p, passes[i].maxw) * kLdsWaves * passes[i].maxw * std::ceil((double)p->Nc / rows);
-    }
-    const bool yes = cells < 2.0e8 && lds_estimate_us(p, dpad) <= 0.95 * gather_estimate_us(p, dpad);
-    if (k <= 64) p->lds_choice[k] = yes ? 1 : 0;
-    return yes;
-}
-
-// Window slots of a cell stream (order[cell_position(wg, wave, j)] = window id or -1): the windows, in their own order, are cut into
-// nwg contiguous blocks of about equal weight (blockPartition = condensed columns) and at most 16 x maxw windows; inside a block
-// they go heaviest-first to the least loaded wavefront that still has a free slot.
-// One workgroup's windows (heaviest first; a split window's parts weigh wt / k each and are placed when it comes up) go to the
-// least loaded wavefront with a free slot, the parts of one window to different wavefronts.  parts_out (if sized) receives
-// part | parts << 8 | scratch index << 16 for the slots of split windows: scratch index of a follower = its own, of part 0 = its first follower's.
-static bool lds_deal_workgroup(int g, int maxw, const std::vector<int32_t>& items, const std::vector<uint8_t>& k, const std::vector<double>& wt,
-                               std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit) {
-    double load[kLdsWaves] = {0};
-    int used[kLdsWaves] = {0};
-    uint32_t next_fol = 0;
-    for (const int32_t w : items) {
-        const int kk = k.empty() ? 1 : k[(size_t)w];
-        uint32_t taken = 0u;                         // wavefronts that hold a part of this window
-        const uint32_t fol0 = next_fol;
-        for (int part = 0; part < kk; ++part) {
-            int best = -1;
-            for (int v = 0; v < kLdsWaves; ++v)
-                if (used[v] < maxw && !((taken >> v) & 1u) && (best < 0 || load[v] < load[best])) best = v;
-            if (best < 0)   // (every free slot sits on a wavefront that already holds a part of this window)
-                for (int v = 0; v < kLdsWaves; ++v) if (used[v] < maxw && (best < 0 || load[v] < load[best])) best = v;
-            if (best < 0) return false;   // more items than slots: the caller's accounting is off - it falls back to a placement without parts
-            const size_t pos = (size_t)cell_position(g, best, used[best], maxw);
-            order[pos] = w;
-            if (kk > 1) parts_out[pos] = (uint32_t)part | ((uint32_t)kk << 8) | ((part == 0 ? fol0 : fol0 + (uint32_t)part - 1u) << 16);
-            taken |= 1u << best;
-            load[best] += wt[(size_t)w] / kk;
-            ++used[best];
-        }
-        if (kk > 1) { next_fol += (uint32_t)kk - 1u; ++nsplit; }
-    }
-    return true;
-}
-static bool lds_place_windows(const tcgnn_plan* p, int nwg, int maxw, std::vector<int32_t>& order, std::vector<uint32_t>& parts_out, int& nsplit,
-                              const std::vector<double>& exact, int mode) {
-    const int nw = p->nw_eff, cap = kLdsWaves * maxw;
-    order.assign((size_t)nwg * cap, -1);
-    parts_out.clear();
-    nsplit = 0;
-    // Hub windows (power-law graphs numbered by degree) sit next to each other: a contiguous block of them fills a few wavefronts of
-    // its workgroup and leaves the rest idle, so the workgroup runs several times longer than the mean (R-MAT, Reddit shape: 1.20 ms
-    // against 0.85 ms).  When the heaviest window is far above the mean the windows are instead dealt heaviest first, boustrophedon-wise
-    // over workgroups and wavefronts - every workgroup gets one hub and a share of the light windows.  TCGNN_LDS_PLACE=global|local forces it.
-    if (mode == kPlaceGlobal) {
-        std::vector<uint8_t> k;
-        const int extra = lds_split_parts(p, maxw, &k, &exact);
-        const char* const place_env = getenv("TCGNN_LDS_PLACE_DEAL");   // A/B aid: the r01 boustrophedon deal when no window is split
-        if (extra == 0 && place_env && atoi(place_env) > 0) {
-            std::vector<int32_t> idx((size_t)nw);
-            std::iota(idx.begin(), idx.end(), 0);
-            std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return p->h_bp[(size_t)x] > p->h_bp[(size_t)y]; });
-            for (int q = 0; q < nw; ++q) {
-                const int row = q / nwg, c = q % nwg;
-                const int wg = (row & 1) ? nwg - 1 - c : c, j = row / kLdsWaves, wv = row % kLdsWaves;
-                order[(size_t)cell_position(wg, (j & 1) ? kLdsWaves - 1 - wv : wv, j, maxw)] = idx[(size_t)q];
-            }
-            return true;
-        }
-        // With split windows: longest-processing-time placement.  Windows (a split one with all its parts) go heaviest first to the
-        // least loaded workgroup that has the slots; inside a workgroup the items (whole windows and parts) go heaviest first to
-        // the least loaded wavefront with a free slot, the parts of one window to different wavefronts.
-        const std::vector<double>& wt = exact;
-        std::vector<int32_t> idx((size_t)nw);
-        std::iota(idx.begin(), idx.end(), 0);
-        std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
-        std::vector<double> wg_load((size_t)nwg, 0.0);
-        std::vector<int> wg_free((size_t)nwg, cap), wg_fol((size_t)nwg, 0);
-        std::vector<std::vector<int32_t>> wg_items((size_t)nwg);
-        for (int q = 0; q < nw; ++q) {
-            const int w = idx[(size_t)q];
-            int kk = k[(size_t)w];
-            int best = -1;
-            for (int pass = 0; pass < 2 && best < 0; ++pass) {   // (second pass: the window whole, wherever one slot is free)
-                if (pass == 1) { kk = 1; k[(size_t)w] = 1; }
-                for (int g = 0; g < nwg; ++g)
-                    if (wg_free[(size_t)g] >= kk && wg_fol[(size_t)g] + kk - 1 <= kLdsMaxFollowers && (best < 0 || wg_load[(size_t)g] < wg_load[(size_t)best])) best = g;
-            }
-            if (best < 0) return false;
-            wg_load[(size_t)best] += wt[(size_t)w];
-            wg_free[(size_t)best] -= kk;
-            wg_fol[(size_t)best] += kk - 1;
-            wg_items[(size_t)best].push_back(w);
-        }
-        if (extra > 0) parts_out.assign((size_t)nwg * cap, 0u); else k.clear();
-        for (int g = 0; g < nwg; ++g)
-            if (!lds_deal_workgroup(g, maxw, wg_items[(size_t)g], k, wt, order, parts_out, nsplit)) return false;
-        if (nsplit == 0) parts_out.clear();
-        return true;
-    }
-    // weight of a window = the tiles it is likely to cost the LDS-resident walk: its condensed columns spread over the column
-    // ranges (a cell with a handful of columns still costs a whole tile step), not the column count alone
-    const std::vector<double>& wt = exact;
-    double total = 0;
-    for (int w = 0; w < nw; ++w) total += wt[(size_t)w];
-    std::vector<uint8_t> k;
-    const int extra = mode == kPlaceLocalSplit ? lds_split_parts(p, maxw, &k, &exact) : 0;
-    if (extra > 0) {
-        // the stream has nwg * cap slots (lds_workgroups counted the parts with the modelled weights; the exact ones may ask for
-        // more): take parts back, from the most divided windows first, until everything fits
-        int64_t slots = 0;
-        for (int w = 0; w < nw; ++w) slots += k[(size_t)w];
-        for (int level = kLdsMaxParts; slots > (int64_t)nwg * cap && level > 1; --level)
-            for (int w = 0; w < nw && slots > (int64_t)nwg * cap; ++w)
-                if (k[(size_t)w] == level) { --k[(size_t)w]; --slots; }
-        parts_out.assign((size_t)nwg * cap, 0u);
-    } else k.clear();
-    std::vector<int64_t> slots_after((size_t)nw + 1, 0);   // slots window w and the windows after it need (an upper bound: parts may still be taken back)
-    for (int w = nw - 1; w >= 0; --w) slots_after[(size_t)w] = slots_after[(size_t)w + 1] + (k.empty() ? 1 : k[(size_t)w]);
-    std::vector<int32_t> blk;   // windows of the block being dealt
-    double acc = 0;
-    int wg = 0, blk_slots = 0, blk_fol = 0;
-    bool ok = true;
-    static const int natural = [] { const char* e = getenv("TCGNN_LDS_DEAL_NATURAL"); return e ? atoi(e) : 1; }();
-    auto deal = [&]() {
-        // Even windows are dealt in their own order (least loaded wavefront first = round-robin): a block that spans two communities
-        // then gives every wavefront its share of both, and in a range of either community all sixteen are busy.  Sorting by
-        // weight first is for blocks with windows far above the others.
-        double mx = 0, sum = 0;
-        for (const int32_t w : blk) { mx = std::max(mx, wt[(size_t)w]); sum += wt[(size_t)w]; }
-        if (!natural) std::stable_sort(blk.begin(), blk.end(), [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
-        else if (mx * (double)blk.size() > 1.5 * sum) {   // the windows far above the mean first, heaviest first; the others keep their order
-            const double heavy = 2.0 * sum / (double)blk.size();
-            auto mid = std::stable_partition(blk.begin(), blk.end(), [&](int32_t x) { return wt[(size_t)x] > heavy; });
-            std::stable_sort(blk.begin(), mid, [&](int32_t x, int32_t y) { return wt[(size_t)x] > wt[(size_t)y]; });
-        }
-        ok = lds_deal_workgroup(wg, maxw, blk, k, wt, order, parts_out, nsplit) && ok;
-        blk.clear(); blk_slots = 0; blk_fol = 0;
-    };
-    // invariant: the slots still needed fit into the free slots of this block plus the workgroups left
-    for (int w = 0; w < nw && ok; ++w) {
-        int kk = k.empty() ? 1 : k[(size_t)w];
-        const int wgs_left0 = nwg - (wg + 1);
-        if (kk > 1 && blk_fol + kk - 1 > kLdsMaxFollowers) { k[(size_t)w] = 1; kk = 1; }            // (scratch of the workgroup is full: this one stays whole)
-        if (blk_slots + kk > cap) {
-            // closing the block leaves its free slots unused: only if what is left still fits into the workgroups behind it
-            if (wgs_left0 > 0 && slots_after[(size_t)w] <= (int64_t)wgs_left0 * cap) { deal(); ++wg; }
-            else { if (kk > 1) k[(size_t)w] = 1; kk = 1; }
-            if (blk_slots + kk > cap) { ok = false; break; }
-        }
-        blk.push_back(w);
-        blk_slots += kk; blk_fol += kk - 1;
-        acc += wt[(size_t)w];
-        const int wgs_left = nwg - (wg + 1);
-        const bool full = blk_slots == cap;
-        const bool heavy_enough = acc >= total * (double)(wg + 1) / nwg;
-        if (wgs_left > 0 && (full || (heavy_enough && slots_after[(size_t)w + 1] <= (int64_t)wgs_left * cap))) { deal(); ++wg; }
-    }
-    if (ok && !blk.empty()) deal();
-    if (nsplit == 0) parts_out.clear();
-    return ok;
-}
-
-static int build_lds_cells(tcgnn_plan* p, hipStream_t stream, int slot) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (p->lds[slot].nranges > 0) return TCGNN_OK;
-    if (p->nw_eff <= 0 || p->Nc <= 0) return fail(TCGNN_ERR_INVALID_ARG, "LDS-range SpMM: empty graph");
-    // the stream is cut from the packed tile stream (cols / mask) or, slot kLdsValSlot, from the single-edge one, whose K slots also
-    // carry the CSR position of their edge: that index follows every slot into the tiles (s_eidx / d_eidx)
-    const bool val = slot == kLdsValSlot;
-    if (val && !p->d_xwb_ptr) return fail(TCGNN_ERR_INVALID_ARG, "edge-valued LDS-resident SpMM: the single-edge stream has not been built");
-    const int64_t* const s_wb = val ? p->d_xwb_ptr : p->d_wb_ptr;
-    const int32_t* const s_cols = val ? p->d_xcols : p->d_cols;
-    const uint32_t* const s_mask = val ? p->d_xmask : p->d_mask;
-    const int32_t* const s_eidx = val ? p->d_xeidx : nullptr;
-    int32_t *d_eidx = nullptr, *d_cold_eidx = nullptr;
-    const int maxw = lds_stream_maxw(slot);
-    const int rows = lds_stream_buf_rows(slot) - 8;          // data rows of a range
-    const int nranges = (p->Nc + rows - 1) / rows;
-    const int per_wg = kLdsWaves * maxw;
-    const int nwg = lds_workgroups(p, maxw);
-    const int nw = nwg * per_wg;                              // window SLOTS of this stream
-    const int64_t ncell = (int64_t)nwg * nranges * per_wg;
-    uint32_t *d_cnt = nullptr, *d_firstq = nullptr, *d_tiles = nullptr;
-    int32_t* d_sorder = nullptr;
-    uint32_t* d_parts_guard = nullptr;   // (set below; freed by bail)
-    auto bail = [&](int rc) { (void)hipFree(d_cnt); (void)hipFree(d_firstq); (void)hipFree(d_tiles); (void)hipFree(d_sorder); (void)hipFree(d_parts_guard); return rc; };
-    // exact weight of every window in THIS stream: the tiles it will cost (at least one, so empty windows still take a slot's worth)
-    std::vector<double> exact((size_t)p->nw_eff, 1.0);
-    {
-        uint32_t* d_wt = nullptr;
-        std::vector<uint32_t> h_wt((size_t)p->nw_eff, 0u);
-        hipError_t e0 = hipMalloc(&d_wt, h_wt.size() * sizeof(uint32_t));
-        if (e0 == hipSuccess) e0 = hipMemsetAsync(d_wt, 0, h_wt.size() * sizeof(uint32_t), stream);
-        if (e0 == hipSuccess) {
-            const int64_t nth = (int64_t)p->nw_eff * nranges;
-            hipLaunchKernelGGL(window_tiles_kernel, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, stream, s_wb, s_cols, p->nw_eff, nranges, p->Nc, rows, d_wt);
-            e0 = hipGetLastError();
-        }
-        if (e0 == hipSuccess) e0 = hipMemcpyAsync(h_wt.data(), d_wt, h_wt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e0 == hipSuccess) e0 = hipStreamSynchronize(stream);
-        (void)hipFree(d_wt);
-        if (e0 != hipSuccess) return fail(e0 == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "window weights: %s", hipGetErrorString(e0));
-        for (size_t w = 0; w < h_wt.size(); ++w) exact[w] = std::max<double>(1.0, h_wt[w]);
-    }
-    // ---- candidate placements: window slots, columns per cell, columns and busiest-wavefront tiles per (workgroup, range) pair,
-    //      and from those an estimate of the kernel time (+ the cold remainder's); the cheapest is built
-    const int64_t npairs_all = (int64_t)nwg * nranges;
-    struct Cand {
-        int mode = kPlaceLocal, nsplit = 0;
-        uint32_t hot_min = 1u;
-        double est_us = 0;
-        std::vector<int32_t> sorder;
-        std::vector<uint32_t> sparts, paircols, pairmax, pairover, pairtiles;   // pairover: [2][pairs] columns beyond 32 / 64 per cell
-        uint32_t *d_cellcols = nullptr, *d_firstq = nullptr, *d_parts = nullptr;
-        int32_t* d_sorder = nullptr;
-        void release() { (void)hipFree(d_cellcols); (void)hipFree(d_firstq); (void)hipFree(d_parts); (void)hipFree(d_sorder); d_cellcols = d_firstq = d_parts = nullptr; d_sorder = nullptr; }
-    };
-    const char* const verbose_env0 = getenv("TCGNN_VERBOSE");
-    const bool verbose0 = verbose_env0 && atoi(verbose_env0) > 0;
-    auto prepare = [&](int mode, Cand& c) -> hipError_t {
-        c.mode = mode;
-        if (!lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, mode)) {   // (a placement with parts that ran out of slots)
-            c.mode = kPlaceLocal;
-            if (!lds_place_windows(p, nwg, maxw, c.sorder, c.sparts, c.nsplit, exact, kPlaceLocal)) return hipErrorInvalidValue;
-        }
-        // threshold: a range step costs a workgroup ~1.7 us (8-window layout, two passes over 256 CUs: ~13 ns of chip time) or
-        // ~1 us (4-window layout, one pass: ~4 ns), a column in the gather walk ~10 ps of chip time.  Forcing the LDS-resident walk
-        // (mode 3: tests, timing) keeps every pair that holds a column, and so does the graph-wide placement (no locality to split
-        // on: every pair holds about the same share); TCGNN_LDS_HOT_COLS overrides.
-        c.hot_min = maxw == kLdsMaxW2 ? 1000u : 400u;
-        if (g_spmm_mode == 3 || c.mode == kPlaceGlobal) c.hot_min = 1u;
-        if (const char* env = getenv("TCGNN_LDS_HOT_COLS")) c.hot_min = (uint32_t)std::max(1, atoi(env));
-        uint32_t *d_pc = nullptr, *d_pm = nullptr, *d_po = nullptr, *d_pt = nullptr;
-        hipError_t e = hipMalloc(&c.d_cellcols, (size_t)(ncell + 1) * sizeof(uint32_t));
-        if (e == hipSuccess && c.nsplit > 0) {
-            e = hipMalloc(&c.d_parts, c.sparts.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpyAsync(c.d_parts, c.sparts.data(), c.sparts.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-        }
-        if (e == hipSuccess) e = hipMalloc(&c.d_firstq, (size_t)nw * nranges * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&c.d_sorder, c.sorder.size() * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_pc, (size_t)npairs_all * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_pm, (size_t)npairs_all * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_po, (size_t)npairs_all * 2 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_pt, (size_t)npairs_all * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpyAsync(c.d_sorder, c.sorder.data(), c.sorder.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipMemsetAsync(c.d_cellcols, 0, (size_t)(ncell + 1) * sizeof(uint32_t), stream);
-        std::vector<uint32_t>& pairmax = c.pairmax;
-        pairmax.resize((size_t)npairs_all);
-        c.paircols.resize((size_t)npairs_all);
-        c.pairover.resize((size_t)npairs_all * 2);
-        c.pairtiles.resize((size_t)npairs_all);
-        if (e == hipSuccess) {
-            const int64_t nthreads = (int64_t)nw * nranges;
-            hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, s_wb, c.d_sorder, s_cols, nw, nwg,
-                               nranges, p->Nc, maxw, rows, c.d_cellcols, c.d_firstq, c.d_parts);
-            hipLaunchKernelGGL(cell_pair_cols_kernel, dim3((unsigned)((npairs_all + 255) / 256)), dim3(256), 0, stream, c.d_cellcols, npairs_all, per_wg, maxw, d_pc, d_pm, d_po, d_pt);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(c.paircols.data(), d_pc, c.paircols.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c.pairover.data(), d_po, c.pairover.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c.pairtiles.data(), d_pt, c.pairtiles.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(pairmax.data(), d_pm, pairmax.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_pc); (void)hipFree(d_pm); (void)hipFree(d_po); (void)hipFree(d_pt);
-        if (e != hipSuccess) return e;
-        // every range ends at a barrier: a workgroup's time is the sum over its hot ranges of a fixed part and its busiest
-        // wavefront's tiles (constants of lds_estimate_us); the kernel lasts as long as its slowest workgroup, times the rounds
-        // beyond one workgroup per CU; the cold remainder's columns go through a gather walk at ~20 ps each.
-        const double rounds = std::max(1.0, std::ceil((double)nwg * (maxw == kLdsMaxW2 ? 2 : 1) / std::max(p->num_cus, 1)));
-        auto estimate = [&](uint32_t hot_min) {
-            double worst = 0, cold = 0;
-            for (int wg = 0; wg < nwg; ++wg) {
-                double t = 0;
-                for (int r = 0; r < nranges; ++r) {
-                    const size_t k = (size_t)wg * nranges + r;
-                    if (c.paircols[k] >= hot_min) t += 0.80 + 0.135 * pairmax[k]; else cold += c.paircols[k];
-                }
-                worst = std::max(worst, t);
-            }
-            return worst * rounds + cold * 20e-6;
-        };
-        c.est_us = estimate(c.hot_min);
-        if (verbose0 && c.mode != kPlaceGlobal)
-            for (uint32_t h : {1u, 125u, 250u, 500u, 1000u, 2000u}) fprintf(stderr, "[tcgnn]   placement %d, hot threshold %u: estimated %.0f us\n", c.mode, h, estimate(h));
-        return hipSuccess;
-    };
-    Cand best;
-    {
-        const int forced = lds_place_forced();
-        const bool hubs = lds_has_hubs(p);
-        hipError_t e0 = prepare(forced >= 0 ? forced : (hubs ? kPlaceGlobal : kPlaceLocal), best);
-        if (e0 == hipSuccess && forced < 0 && hubs) {
-            Cand other;
-            e0 = prepare(kPlaceLocalSplit, other);
-            if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: estimated %.0f us longest-first over the graph, %.0f us contiguous blocks (+ cold remainder)\n", slot, best.est_us, other.est_us);
-            if (e0 == hipSuccess && other.est_us < best.est_us) std::swap(best, other);
-            other.release();
-        }
-        if (e0 != hipSuccess) { best.release(); return fail(e0 == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e0)); }
-    }
-    std::vector<int32_t>& sorder = best.sorder;
-    std::vector<uint32_t>& sparts = best.sparts;
-    const int nsplit = best.nsplit;
-    const uint32_t hot_min = best.hot_min;
-    const std::vector<uint32_t>& paircols = best.paircols;
-    uint32_t* d_parts = best.d_parts;
-    d_parts_guard = d_parts;
-    d_firstq = best.d_firstq;
-    d_sorder = best.d_sorder;
-    uint32_t* d_cellcols = best.d_cellcols;   // (the dense table of step one holds columns per cell)
-    hipError_t e = hipSuccess;
-    // ---- hot / cold: a (workgroup, range) pair is worth a range fill only if enough of the workgroup's columns fall into it
-    uint32_t* d_paircols = nullptr;
-    int32_t *d_kmap = nullptr, *d_rbase = nullptr, *d_rlist = nullptr;
-    uint32_t* d_coldcols = nullptr;
-    int64_t* d_cold_ptr = nullptr;
-    int32_t* d_ccols = nullptr;
-    uint32_t* d_cmask = nullptr;
-    uint32_t* d_flat = nullptr;
-    auto bail2 = [&](int rc) {
-        (void)hipFree(d_flat); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_rbase); (void)hipFree(d_rlist); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
-        (void)hipFree(d_cold_ptr); (void)hipFree(d_ccols); (void)hipFree(d_cmask); (void)hipFree(d_eidx); (void)hipFree(d_cold_eidx);
-        return bail(rc);
-    };
-    e = hipMalloc(&d_kmap, (size_t)npairs_all * sizeof(int32_t));
-    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
-    std::vector<int32_t> kmap((size_t)npairs_all, -1), rbase((size_t)nwg + 1, 0), rlist;
-    int64_t hot_cols = 0, cold_cols = 0;
-    for (int wg = 0; wg < nwg; ++wg) {
-        rbase[(size_t)wg] = (int32_t)rlist.size();
-        for (int r = 0; r < nranges; ++r) {
-            const uint32_t c = paircols[(size_t)wg * nranges + r];
-            if (c >= hot_min) { kmap[(size_t)wg * nranges + r] = (int32_t)rlist.size(); rlist.push_back(r); hot_cols += c; }
-            else cold_cols += c;
-        }
-    }
-    rbase[(size_t)nwg] = (int32_t)rlist.size();
-    const int64_t npairs = (int64_t)rlist.size();
-    rlist.resize(rlist.size() + 4, 0);
-    const int64_t ncell_hot = npairs * per_wg;
-    e = hipMalloc(&d_cnt, (size_t)(ncell_hot + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_rbase, rbase.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_rlist, rlist.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (size_t)(ncell_hot + 1) * sizeof(uint32_t), stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_kmap, kmap.data(), kmap.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rbase, rbase.data(), rbase.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rlist, rlist.data(), rlist.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
-    // ---- flat or ordinary (tcgnn_lds_flat.inc): a flat stream gives every cell of a hot pair exactly tpc tiles and sends what
-    //      a cell holds beyond 32 tpc columns to the cold remainder.  Taken when that costs few columns (the cold remainder of a
-    //      flat stream is added by a latency-bound kernel) and no more tile steps than the ordinary stream's; never with split
-    //      hub windows (their cells are nowhere near uniform).  TCGNN_LDS_FLAT=0 / 1 / 2 forces ordinary / one / two tiles per cell.
-    int flat_tpc = 0;
-    int64_t over_cols = 0;
-    {
-        // (what a range lasts is its busiest wavefront's tile steps - every range ends at a barrier: pairmax for the ordinary
-        //  stream, maxw x tpc for a flat one, whose empty window slots are skipped but whose wavefronts all wait for a full one)
-        int64_t classic_tiles = 0, classic_steps = 0, over[2] = {0, 0};
-        for (int64_t k = 0; k < npairs_all; ++k)
-            if (kmap[(size_t)k] >= 0) { classic_tiles += best.pairtiles[(size_t)k]; classic_steps += best.pairmax[(size_t)k];
-                                        over[0] += best.pairover[(size_t)k]; over[1] += best.pairover[(size_t)(npairs_all + k)]; }
-        const char* fenv = getenv("TCGNN_LDS_FLAT");
-        const int forced_flat = fenv ? atoi(fenv) : -1;
-        if (nsplit == 0 && npairs > 0 && forced_flat != 0) {
-            for (int tpc = 1; tpc <= 2 && !flat_tpc; ++tpc) {
-                if (maxw * tpc > 16) break;
-                const int64_t flat_tiles = ncell_hot * tpc;
-                const bool few_cold = (double)(cold_cols + over[tpc - 1]) <= 0.04 * (double)std::max<int64_t>(hot_cols + cold_cols, 1);
-                (void)flat_tiles;
-                // (a flat step costs ~0.75 of an ordinary one - 1.46 against 1.84 us per range of ~8 steps on the Reddit shape - and a
-                //  stream of nearly-empty cells, a wide row shard, ties on the count: 627 712 flat steps against 627 699)
-                const bool no_more_steps = (double)(npairs * maxw * tpc) <= 1.2 * (double)std::max<int64_t>(classic_steps, 1);
-                if (forced_flat == tpc || (forced_flat < 0 && few_cold && no_more_steps)) { flat_tpc = tpc; over_cols = over[tpc - 1]; }
-            }
-        }
-        if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: %lld tiles ordinary, %lld steps of the busiest wavefronts; flat would take %lld steps (+%lld columns cold) / %lld (+%lld): %s\n", slot,
-                              (long long)classic_tiles, (long long)classic_steps, (long long)(npairs * maxw), (long long)over[0], (long long)(2 * npairs * maxw), (long long)over[1],
-                              flat_tpc ? (flat_tpc == 1 ? "flat, 1 tile per cell" : "flat, 2 tiles per cell") : "ordinary");
-    }
-    if (flat_tpc && !getenv("TCGNN_LDS_FLAT")) {
-        // ... nor where ONE window would leave a long remainder behind (a hub row: its cells overflow in every range, and the
-        // remainder of a window is one wavefront's serial work - a 24 k-degree hub cost the flat walk 0.72 ms against 0.61):
-        // the remainder is counted with the flat cap before anything is built
-        uint32_t* d_trial = nullptr;
-        std::vector<uint32_t> trial((size_t)p->nw_eff, 0u);
-        e = hipMalloc(&d_trial, trial.size() * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(d_trial, 0, trial.size() * sizeof(uint32_t), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_trial, (uint32_t)(32 * flat_tpc));
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(trial.data(), d_trial, trial.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_trial);
-        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell table: %s", hipGetErrorString(e)));
-        uint32_t worst = 0;
-        for (uint32_t c : trial) worst = std::max(worst, (c + 31u) / 32u);
-        if (worst > 16u) {
-            if (verbose0) fprintf(stderr, "[tcgnn] cell stream %d: ordinary after all - one window would leave %u cold tiles behind\n", slot, worst);
-            flat_tpc = 0; over_cols = 0;
-        }
-    }
-    if (val && flat_tpc != 1)   // (spmm_lds_val_kernel walks flat streams with one tile per cell only; the caller keeps the gather walks)
-        return bail2(fail(TCGNN_ERR_UNSUPPORTED, "edge-valued LDS-resident SpMM: the single-edge cells of this graph are not uniform enough for a flat stream"));
-    hot_cols -= over_cols; cold_cols += over_cols;
-    if (ncell > 0) hipLaunchKernelGGL(cell_compact_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, npairs_all, per_wg, d_cnt);
-    std::vector<uint32_t> cnt((size_t)ncell_hot + 1);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return bail2(fail(TCGNN_ERR_HIP, "cell count: %s", hipGetErrorString(e)));
-    uint64_t run = 0;
-    if (flat_tpc) run = (uint64_t)ncell_hot * (uint64_t)flat_tpc;   // (positions are computed: the table is not kept)
-    else for (size_t k = 0; k < cnt.size(); ++k) { const uint32_t c = cnt[k]; cnt[k] = (uint32_t)run; run += c; }
-    if (run >= (1ull << 32)) return bail2(fail(TCGNN_ERR_BAD_GRAPH, "LDS-range SpMM: %llu tiles overflow the 32-bit cell table", (unsigned long long)run));
-    const int64_t ntiles = (int64_t)run;
-    const int64_t nwords = std::max<int64_t>(ntiles, 1) * kCellWords;
-    e = hipMalloc(&d_tiles, (size_t)nwords * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell stream (%lld tiles): %s", (long long)ntiles, hipGetErrorString(e)));
-    hipLaunchKernelGGL(cell_init_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, nwords, rows);
-    if (val) {   // (flat only: the caller gives the stream up otherwise)
-        e = hipMalloc(&d_eidx, (size_t)std::max<int64_t>(ntiles, 1) * 32 * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(d_eidx, 0xff, (size_t)std::max<int64_t>(ntiles, 1) * 32 * sizeof(int32_t), stream);
-        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "edge index of the cell stream: %s", hipGetErrorString(e)));
-    }
-    hipLaunchKernelGGL(cell_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, s_wb, d_sorder, s_cols, s_mask, nwg, nranges, p->Nc,
-                       maxw, rows, d_cnt, d_firstq, d_tiles, d_kmap, d_parts, d_cellcols, flat_tpc, s_eidx, d_eidx);
-    if (ntiles > 0) hipLaunchKernelGGL(cell_optimize_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, d_tiles, ntiles, rows, d_eidx);
-    e = hipGetLastError();
-    if (e == hipSuccess && flat_tpc) {   // tiles -> per-(pair, wavefront) metadata blocks; the ordinary tiles and the cell table go
-        e = hipMalloc(&d_flat, (size_t)nwords * sizeof(uint32_t));
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(flat_transpose_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, d_tiles, d_flat, npairs * kLdsWaves, maxw * flat_tpc);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_tiles); d_tiles = nullptr;
-        (void)hipFree(d_cnt); d_cnt = nullptr;
-        if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "flat cell stream: %s", hipGetErrorString(e)));
-    }
-    // ---- the cold remainder, re-condensed per window for the gather walk
-    int64_t cold_tiles = 0, cold_max = 0;
-    size_t cold_bytes = 0;
-    std::vector<int64_t> cptr;
-    if (e == hipSuccess && cold_cols > 0) {
-        const int nwe = p->nw_eff;
-        std::vector<uint32_t> coldc((size_t)nwe, 0);
-        e = hipMalloc(&d_coldcols, (size_t)nwe * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(d_coldcols, 0, (size_t)nwe * sizeof(uint32_t), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(cell_cold_count_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, d_cellcols, d_kmap, d_sorder, nw, nranges, maxw, d_coldcols,
-                               (uint32_t)(32 * flat_tpc));
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(coldc.data(), d_coldcols, coldc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        cptr.assign((size_t)nwe + 1, 0);
-        for (int w = 0; w < nwe; ++w) { cptr[(size_t)w + 1] = cptr[(size_t)w] + (coldc[(size_t)w] + 31) / 32; cold_max = std::max<int64_t>(cold_max, (coldc[(size_t)w] + 31) / 32); }
-        cold_tiles = cptr[(size_t)nwe];
-        const size_t b_ptr = cptr.size() * sizeof(int64_t), b_c = (size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols * 4, b_m = (size_t)std::max<int64_t>(cold_tiles, 1) * kWinRows * 4;
-        if (e == hipSuccess) e = hipMalloc(&d_cold_ptr, b_ptr);
-        if (e == hipSuccess) e = hipMalloc(&d_ccols, b_c);
-        if (e == hipSuccess) e = hipMalloc(&d_cmask, b_m);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_cold_ptr, cptr.data(), b_ptr, hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_cmask, 0, b_m, stream);
-        if (e == hipSuccess) {
-            // (padding columns of a window's last tile point at the all-zero sentinel row, like pack_kernel's)
-            std::vector<int32_t> fillv((size_t)std::max<int64_t>(cold_tiles, 1) * kWbCols, p->Nc);
-            e = hipMemcpyAsync(d_ccols, fillv.data(), b_c, hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        }
-        if (e == hipSuccess && val) {
-            e = hipMalloc(&d_cold_eidx, (size_t)std::max<int64_t>(cold_tiles, 1) * 32 * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMemsetAsync(d_cold_eidx, 0xff, (size_t)std::max<int64_t>(cold_tiles, 1) * 32 * sizeof(int32_t), stream);
-        }
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(cell_cold_fill_kernel, dim3((unsigned)nw), dim3(256), 0, stream, s_wb, d_sorder, s_cols, s_mask, d_kmap, nranges, p->Nc,
-                               maxw, rows, d_cold_ptr, d_ccols, d_cmask, d_parts, d_firstq, (uint32_t)(32 * flat_tpc), s_eidx, d_cold_eidx);
-            e = hipGetLastError();
-        }
-        cold_bytes = b_ptr + b_c + b_m;
-    }
-    // ---- a flat stream whose layout leaves 16 x NT KB of LDS: the remainder as per-wavefront record lists, multiplied inside the
-    //      flat kernel one tile per range (tcgnn_lds_flat.inc: cold_step) instead of by spmm_cold_planar_kernel afterwards
-    int32_t* d_wcold_ptr = nullptr;
-    uint32_t *d_wcold = nullptr, *d_wlist = nullptr;
-    static const int wcold_enabled = [] { const char* en = getenv("TCGNN_LDS_COLD_INSIDE"); return en ? atoi(en) : 1; }();
-    if (e == hipSuccess && !val && flat_tpc && cold_tiles > 0 && cold_tiles < (1ll << 28) && wcold_enabled && flat_cold_fits(lds_stream_nt(slot), maxw, flat_tpc)) {
-        std::vector<int32_t> wptr((size_t)nwg * kLdsWaves + 1, 0);
-        std::vector<uint32_t> wlist;
-        wlist.reserve((size_t)cold_tiles);
-        for (int g2 = 0; g2 < nwg; ++g2)
-            for (int v = 0; v < kLdsWaves; ++v) {
-                wptr[(size_t)g2 * kLdsWaves + v] = (int32_t)wlist.size();
-                for (int j = 0; j < maxw; ++j) {
-                    const int w = sorder[(size_t)cell_position(g2, v, j, maxw)];
-                    if (w < 0) continue;
-                    for (int64_t t = cptr[(size_t)w]; t < cptr[(size_t)w + 1]; ++t) wlist.push_back((uint32_t)t | ((uint32_t)j << 28));
-                }
-            }
-        wptr[(size_t)nwg * kLdsWaves] = (int32_t)wlist.size();
-        e = hipMalloc(&d_wcold_ptr, wptr.size() * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_wlist, std::max<size_t>(wlist.size(), 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&d_wcold, std::max<size_t>(wlist.size(), 1) * 64 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_wcold_ptr, wptr.data(), wptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess && !wlist.empty()) e = hipMemcpyAsync(d_wlist, wlist.data(), wlist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess && !wlist.empty()) {
-            const int64_t nwordsw = (int64_t)wlist.size() * 64;
-            hipLaunchKernelGGL(flat_cold_records_kernel, dim3((unsigned)((nwordsw + 255) / 256)), dim3(256), 0, stream, d_wlist, (int64_t)wlist.size(), d_ccols, d_cmask, d_wcold);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_wlist);
-        if (e != hipSuccess) { (void)hipFree(d_wcold_ptr); (void)hipFree(d_wcold); d_wcold_ptr = nullptr; d_wcold = nullptr; }
-        else cold_bytes += wptr.size() * sizeof(int32_t) + wlist.size() * 256;
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // host vectors must outlive their copies
-    if (e != hipSuccess) return bail2(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "cell fill: %s", hipGetErrorString(e)));
-    (void)hipFree(d_firstq); (void)hipFree(d_paircols); (void)hipFree(d_kmap); (void)hipFree(d_cellcols); (void)hipFree(d_coldcols);
-    tcgnn_plan::CellStream& cs = p->lds[slot];
-    cs.d_order = d_sorder;
-    cs.d_cell_ptr = d_cnt; cs.d_cell_tiles = d_tiles;
-    cs.flat_tpc = flat_tpc; cs.d_flat = d_flat;
-    cs.d_wcold_ptr = d_wcold_ptr; cs.d_wcold = d_wcold;
-    cs.d_eidx = d_eidx; cs.d_cold_eidx = d_cold_eidx;
-    cs.nwg = nwg; cs.tiles = ntiles;
-    cs.npairs = (int32_t)npairs; cs.d_rbase = d_rbase; cs.d_rlist = d_rlist;
-    cs.cold_tiles = cold_tiles; cs.hot_cols = hot_cols; cs.cold_cols = cold_cols; cs.cold_max = cold_max;
-    cs.d_parts = d_parts; cs.nsplit = nsplit;
-    const char* const verbose_env = getenv("TCGNN_VERBOSE");   // (read per build: builds are rare, and tests switch it on)
-    const bool verbose = verbose_env && atoi(verbose_env) > 0;
-    if (verbose)
-        fprintf(stderr, "[tcgnn] cell stream %d (%d windows per wavefront, %d-row ranges): %d workgroups x %d ranges, %lld of %lld pairs hot (>= %u columns), "
-                        "%lld columns hot / %lld cold, %lld tiles + %lld cold gather tiles, placement %s\n",
-                slot, maxw, rows, nwg, nranges, (long long)npairs, (long long)npairs_all, hot_min, (long long)hot_cols, (long long)cold_cols,
-                (long long)ntiles, (long long)cold_tiles, best.mode == kPlaceGlobal ? "longest-first over the graph" : "contiguous blocks");
-    if (verbose && flat_tpc) fprintf(stderr, "[tcgnn]   flat: %d tile(s) per cell, %lld columns beyond the cells' tiles moved to the cold remainder (%s)\n", flat_tpc, (long long)over_cols,
-                                     d_wcold_ptr ? "multiplied inside the kernel, one tile per range" : "added by spmm_cold_planar_kernel");
-    if (verbose && nsplit) fprintf(stderr, "[tcgnn]   %d windows split over several wavefronts\n", nsplit);
-    cs.d_cold_ptr = d_cold_ptr; cs.d_cold_cols = d_ccols; cs.d_cold_mask = d_cmask;
-    p->bytes += (flat_tpc ? 0 : (size_t)(ncell_hot + 1) * sizeof(uint32_t)) + (size_t)nwords * sizeof(uint32_t) + sorder.size() * sizeof(int32_t) +
-                (rbase.size() + rlist.size()) * sizeof(int32_t) + cold_bytes + (nsplit ? sparts.size() * sizeof(uint32_t) : 0) +
-                (val ? (size_t)(std::max<int64_t>(ntiles, 1) + (cold_tiles > 0 ? cold_tiles : 0)) * 32 * sizeof(int32_t) : 0);
-    cs.nranges = nranges;
-    return TCGNN_OK;
-}
-
-// ---- the edge-valued LDS-resident walk (tcgnn_lds_val.inc): single-edge tile stream + its flat cell stream (slot kLdsValSlot).
-// Built on the first edge-valued call that would use it (allocates and synchronises: never inside a graph capture); the answer -
-// usable or not - is remembered in plan->val_choice.
-static int build_val_stream(tcgnn_plan* p, hipStream_t stream) {
-    {
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lock(mu);
-        if (p->val_choice.load(std::memory_order_acquire) >= 0) return TCGNN_OK;
-        if (!p->d_xwb_ptr) {
-            const int nw = p->nw_eff;
-            int32_t *d_ew = nullptr, *d_flags = nullptr;
-            std::vector<int32_t> ew((size_t)nw, 0);
-            hipError_t e = hipMalloc(&d_ew, (size_t)nw * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc(&d_flags, sizeof(int32_t));
-            if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(int32_t), stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(window_edges_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, p->rowptr, p->N, nw, d_ew);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipMemcpyAsync(ew.data(), d_ew, (size_t)nw * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            (void)hipFree(d_ew);
-            std::vector<int64_t> xptr((size_t)nw + 1, 0);
-            for (int w = 0; w < nw; ++w) xptr[(size_t)w + 1] = xptr[(size_t)w] + (ew[(size_t)w] + kWbCols - 1) / kWbCols;
-            const int64_t total = std::max<int64_t>(xptr[(size_t)nw], 1);
-            int64_t* d_xp = nullptr; int32_t *d_xc = nullptr, *d_xe = nullptr; uint32_t* d_xm = nullptr;
-            auto drop = [&]() { (void)hipFree(d_xp); (void)hipFree(d_xc); (void)hipFree(d_xe); (void)hipFree(d_xm); (void)hipFree(d_flags); };
-            if (e == hipSuccess) e = hipMalloc(&d_xp, xptr.size() * sizeof(int64_t));
-            if (e == hipSuccess) e = hipMalloc(&d_xc, (size_t)total * kWbCols * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc(&d_xe, (size_t)total * kWbCols * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc(&d_xm, (size_t)total * kWinRows * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpyAsync(d_xp, xptr.data(), xptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess) e = hipMemsetAsync(d_xe, 0xff, (size_t)total * kWbCols * sizeof(int32_t), stream);
-            if (e == hipSuccess) e = hipMemsetAsync(d_xm, 0, (size_t)total * kWinRows * sizeof(uint32_t), stream);
-            if (e == hipSuccess) {
-                std::vector<int32_t> fillv((size_t)total * kWbCols, p->Nc);   // (padding slots point at the all-zero sentinel row, like pack_kernel's)
-                e = hipMemcpyAsync(d_xc, fillv.data(), fillv.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            }
-            int32_t bad = 0;
-            if (e == hipSuccess && nw > 0) {
-                hipLaunchKernelGGL(expand_edges_kernel, dim3((unsigned)nw), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, p->d_mask, p->d_ebase, d_xp, d_xc, d_xm, d_xe, p->Nc, d_flags);
-                e = hipGetLastError();
-            }
-            if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess || bad) {
-                drop();
-                p->val_choice.store(0, std::memory_order_release);
-                return e == hipSuccess ? TCGNN_OK : fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "single-edge tile stream: %s", hipGetErrorString(e));
-            }
-            (void)hipFree(d_flags);
-            p->d_xwb_ptr = d_xp; p->d_xcols = d_xc; p->d_xmask = d_xm; p->d_xeidx = d_xe; p->total_xwb = xptr[(size_t)nw];
-            p->bytes += xptr.size() * sizeof(int64_t) + (size_t)total * (2 * kWbCols * sizeof(int32_t) + kWinRows * sizeof(uint32_t));
-        }
-    }
-    const int rc = build_lds_cells(p, stream, kLdsValSlot);
-    tcgnn_plan::CellStream& cs = p->lds[kLdsValSlot];
-    bool ok = rc == TCGNN_OK && cs.nranges > 0 && cs.flat_tpc == 1 && cs.nsplit == 0 && cs.d_eidx;
-    if (ok) {   // CSR positions -> 16-bit offsets into each window's run of edges (half the index bytes per call and in the plan)
-        const size_t nt = (size_t)std::max<int64_t>(cs.tiles, 1), nc = (size_t)std::max<int64_t>(cs.cold_tiles, 1);
-        int32_t* d_bad = nullptr; int32_t bad = 0;
-        hipError_t e = hipMalloc(&cs.d_eidx16, nt * 32 * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMalloc(&cs.d_cold_eidx16, nc * 32 * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int32_t), stream);
-        if (e == hipSuccess) e = hipMemsetAsync(cs.d_eidx16, 0xff, nt * 32 * sizeof(uint16_t), stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(val_index16_kernel, dim3((unsigned)(cs.nwg * kLdsWaves * kLdsMaxW2)), dim3(256), 0, stream, p->rowptr, cs.d_order, cs.d_eidx, cs.d_rbase, cs.d_eidx16, p->N,
-                               kLdsMaxW2, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx, cs.d_cold_eidx16, d_bad);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_bad);
-        ok = e == hipSuccess && !bad;
-        if (ok) p->bytes += (nt + nc) * 32 * sizeof(uint16_t);
-    }
-    if (cs.d_eidx) {
-        (void)hipStreamSynchronize(stream);
-        p->bytes -= (size_t)(std::max<int64_t>(cs.tiles, 1) + (cs.cold_tiles > 0 ? cs.cold_tiles : 0)) * 32 * sizeof(int32_t);
-        (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); cs.d_eidx = nullptr; cs.d_cold_eidx = nullptr;
-    }
-    // (the single-edge source is only needed to cut the cell stream: 0.9 GB on the Reddit shape, released here)
-    (void)hipStreamSynchronize(stream);
-    p->bytes -= ((size_t)p->nw_eff + 1) * sizeof(int64_t) + (size_t)std::max<int64_t>(p->total_xwb, 1) * (2 * kWbCols * sizeof(int32_t) + kWinRows * sizeof(uint32_t));
-    (void)hipFree(p->d_xwb_ptr); (void)hipFree(p->d_xcols); (void)hipFree(p->d_xmask); (void)hipFree(p->d_xeidx);
-    p->d_xwb_ptr = nullptr; p->d_xcols = nullptr; p->d_xmask = nullptr; p->d_xeidx = nullptr;
-    p->val_choice.store(ok ? 1 : 0, std::memory_order_release);
-    return (rc == TCGNN_ERR_OOM || rc == TCGNN_ERR_HIP) ? rc : TCGNN_OK;
-}
-// bytes the per-call slot values take behind the planar image (the stream's tiles and its cold tiles, 64 bytes each)
-static size_t val_stream_bytes(const tcgnn_plan* p) {
-    const tcgnn_plan::CellStream& cs = p->lds[kLdsValSlot];
-    if (p->val_choice.load(std::memory_order_acquire) != 1) return 0;
-    return ((size_t)(std::max<int64_t>(cs.tiles, 1) + std::max<int64_t>(cs.cold_tiles, 0)) * 64 + 255) / 256 * 256;
-}
+#include "tcgnn_lds_plan.inc"
 
 // columns one gather-walk launch may cover: the widest row whose pitch the structured descriptor can express, in whole
 // 128-column chunks.  Wider matrices go through the gather walks as independent column blocks (ld = the full row length).
@@ -3529,7 +840,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             // (the per-tile metadata DMA fetches 16 edge-offset words too; binary SpMM never looks at them: the mask array stands in)
             SpmmArgs a{cold->d_cold_ptr, plan->d_order, cold->d_cold_cols, cold->d_cold_mask, reinterpret_cast<const int32_t*>(cold->d_cold_mask), x16_rows, nullptr, hdr, d_Y, plan->N, D, pitch_r, 0, plan->E,
                        plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1};
-            static const int cold_w4 = [] { const char* e = getenv("TCGNN_COLD_W4"); return e ? atoi(e) : 48; }();   // tiles per window from which 4 wavefronts share it (SBM Reddit shape, 25 cold tiles per window: 169 us with one wavefront, 202 with four)
+            constexpr int cold_w4 = 48;   // tiles per window from which 4 wavefronts share it (SBM Reddit shape, 25 cold tiles per window: 169 us with one wavefront, 202 with four)
             // (and a window with hundreds of cold tiles - a hub - is 0.25 us per tile of serial work for one wavefront)
             const int waves = (cold->cold_tiles >= (int64_t)cold_w4 * plan->nw_eff || cold->cold_max >= 512) ? 4 : 1;
             const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
@@ -3555,7 +866,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     KernelTimer timer(plan, stream, blocked ? "spmm_blocked_kernel" : "spmm_kernel");
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
-        if (const char* e = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // tuning experiments only
+        if (const char* e = test_knob("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(e) << 10;   // (tests: several ranges on a graph the oracle can handle)
         int nranges = 1;
         while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
         SpmmBlockedArgs b{a, plan->d_bptr, plan->nbuckets, plan->nbuckets / nranges, nranges, plan->nw_eff, 0};
@@ -3639,7 +950,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
             }
         } else if (blocked) {
             size_t range_bytes = 4 * kRangeTargetBytes;
-            if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
+            if (const char* env = test_knob("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
             int nranges = 1;
             while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
             a.nranges = nranges;
@@ -3761,7 +1072,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     {
         int64_t mx = 0;
         for (int w = 0; w < nw; ++w) mx = std::max<int64_t>(mx, bp[(size_t)w]);
-        static const int order_mode = [] { const char* e = getenv("TCGNN_ORDER"); return e ? atoi(e) : 0; }();   // 0 automatic, 1 heaviest first, 2 XCD-contiguous
+        constexpr int order_mode = 0;   // 0 automatic (1 heaviest first / 2 XCD-contiguous were A/B switches of r02)
         const bool balanced = nw > 0 && mx * nw <= 4 * std::max<int64_t>(p->tc_blocks, 1);
         // A few hubs over an otherwise even graph (communities + hubs): the K windows more than 4x the mean start first, heaviest first
         // (the round-robin dispatch spreads them over the XCDs), the rest follows in XCD-contiguous order.  A continuous skew
@@ -4099,7 +1410,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         // (r03, whole-line gathers: D = 64 1.26 / 1.24 ms at 4 / 8 MB ranges, 1.36 at 2 MB; D = 128 - an image of 60 MB - 2.33 at 2 MB,
         //  2.58 at 4 MB, 3.5 per-window; with XCD affinity 2.01 at 2 or 4 MB)
         size_t range_bytes = x16_bytes > ((size_t)32 << 20) ? 2 * kRangeTargetBytes : 4 * kRangeTargetBytes;
-        if (const char* env = getenv("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
+        if (const char* env = test_knob("TCGNN_RANGE_KB")) range_bytes = (size_t)atol(env) << 10;
         int nranges = 1;
         while (nranges < plan->nbuckets && x16_bytes / nranges > range_bytes) nranges <<= 1;
         a.nranges = nranges;
@@ -4110,7 +1421,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         int nwg = (int)std::min<int64_t>((items + 3) / 4, (int64_t)plan->num_cus * per_cu);
         // XCD affinity (sddmm_kernel; TCGNN_SDDMM_XCD=0 switches it off, read per call: tests compare the two).  Reddit shape:
         // D = 128 2.32 -> 2.01 ms, D = 64 1.36 -> 1.33, D = 16 / 32 -1 .. -2.5 %; before the whole-line gathers it returned nothing.
-        const char* const xenv = getenv("TCGNN_SDDMM_XCD");
+        const char* const xenv = test_knob("TCGNN_SDDMM_XCD");
         // (like the fused kernel's sliced walk it wants every window's tiles spread evenly over the ranges: on the calibrated SBM graph -
         //  22.5 % of a window's edges inside its own community, near_frac 0.3 - the XCD that owns a window's community holds the others
         //  up, 1.43 -> 2.11 ms at D = 64, where an XCD has ONE range; with four ranges per XCD, spread over the graph, the load evens

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the LDS-resident range SpMM (mode 3) on the Reddit shape under the TCGNN_LDS_DBG switches (set in the environment)."""
+"""Time the LDS-resident range SpMM (mode 3) on the Reddit shape under the TCGNN_LDS_DBG switches (set in the environment; the
+phase-timer kernels exist only in a library built with `make -C tc-gnn_atc23_amd/csrc DEBUG_TIMERS=1`)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")): sys.path.insert(0, p)
