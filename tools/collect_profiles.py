@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tc-gnn_atc23_amd"))
-TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
 QUICK = "--quick" in sys.argv
 ALLGEN = "--all-generators" in sys.argv
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + TAG)
@@ -31,7 +31,7 @@ os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
 PMC_GROUPS = [["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"], ["GRBM_GUI_ACTIVE"],
               ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]]
-KERNELS = ("spmm", "sddmm", "agnn_kernel")
+KERNELS = ("spmm", "sddmm", "agnn_kernel", "val_permute")
 
 
 def rocprof(args, cmd, outdir, log):
@@ -66,7 +66,7 @@ def pmc_workload(shape, gen, D):
             for r in csv.DictReader(open(f)):
                 k = r.get("Kernel_Name", "")
                 # (spmm_small_kernel: on these graphs it is the range guard's gated fp32 fallback, which returns at once)
-                if any(s in k for s in KERNELS) and "csr_kernel" not in k and "fallback" not in k and "spmm_small_kernel" not in k:
+                if any(s in k for s in KERNELS) and "csr_kernel" not in k and "fallback" not in k and "wide_patch" not in k and "spmm_small_kernel" not in k:
                     per_kernel[k.split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
         try:
             meta = [l for l in open(log) if l.startswith("E=")][-1].strip()
