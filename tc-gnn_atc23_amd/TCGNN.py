@@ -186,7 +186,8 @@ def range_mode(device=None):
 
 
 def set_range_guard(level):
-    """Not part of the reference API: the range guard's level - 0 off, 1 the SpMM operators only, 2 every operator (default since r04)
+    """Not part of the reference API: the range guard's level - 0 off, 1 the SpMM operators only, 2 (default since r04) also SDDMM and
+    the fused AGNN pair when a matrix has a few lost elements (patched behind the MFMA kernels), 3 strict: any wide matrix in fp32
     (include/tcgnn.h: tcgnn_set_range_guard)."""
     _c.check(_c.lib.tcgnn_set_range_guard(int(level)), "tcgnn_set_range_guard")
 

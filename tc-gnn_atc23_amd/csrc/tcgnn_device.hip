@@ -227,7 +227,9 @@ __device__ __forceinline__ bool range_is_wide_val(const uint32_t* hdr) {
 // fallback kernels (spmm_wide_fallback_kernel, the fp32-MFMA walk).
 static constexpr uint32_t kSparseRows = 48;
 __device__ __forceinline__ bool wide2_sparse(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] <= kSparseRows; }
-__device__ __forceinline__ bool wide2_dense(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] > kSparseRows; }
+// (more dirty rows than the patch takes: at the STRICT level - header word 9 - the MFMA kernel returns and the patch launch does all the
+//  work in plain fp32; at the default level the call stays on the MFMA path and answers to the documented bound, like level 1)
+__device__ __forceinline__ bool wide2_dense(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] > kSparseRows && hdr[9] != 0u; }
 // conversion pass: a thread that met an element losing bits records the row (duplicates are possible: the patch de-duplicates)
 __device__ __forceinline__ void note_dirty_row(uint32_t* hdr, uint32_t nt, int64_t row) {
     if (!hdr || !nt) return;
@@ -526,14 +528,14 @@ static size_t agnn_slice_bytes(const tcgnn_plan* plan, int32_t D) {
 // ---- range guard parameters (range_is_wide): cap = how many lost-precision terms one result can collect at most - the longest row
 // of the graph (SpMM) or 2 D (SDDMM / fused AGNN) - and the power of max|X| in the error bound.  cap 0 = guard off
 // (tcgnn_set_range_guard(0), TCGNN_RANGE_GUARD=0).
-static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 2; }();   // (r04: every operator - the usual wide input costs one patch launch)
+static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 2; }();   // (r04: 2 - the usual wide input of SDDMM / fused AGNN costs one patch launch; 3 = strict)
 struct Guard { uint32_t cap, pow; };
 static Guard guard_spmm(const tcgnn_plan* p) { return {g_range_guard ? (uint32_t)std::max(p->max_degree, 1) : 0u, 1u}; }
 // (level 1, the default: the aggregation operators - binary and edge-valued SpMM, the fused dense update - whose bound is linear in
 //  max|X| and which a training epoch never reaches; level 2 adds SDDMM and the fused AGNN pair, whose bound is QUADRATIC in max|X|:
 //  an AGNN epoch of the reference's unscaled recipe crosses 2^14.5 with a single lost element now and then, and each such call
 //  costs ~25 ms in the CSR fallbacks against 2 ms - so those two answer to the documented bound unless asked to be strict)
-static Guard guard_sddmm(int D) { return {g_range_guard >= 2 ? (uint32_t)(2 * std::max(D, 1)) : 0u, 2u}; }
+static Guard guard_sddmm(int D) { return {g_range_guard >= 2 ? (uint32_t)(2 * std::max(D, 1)) : 0u, 2u | (g_range_guard >= 3 ? 0x100u : 0u)}; }   // (bit 8: strict, header word 9)
 
 // ldx > 0: X (and the gate) is a column block of a wider row-major matrix with that row stride; the scale words in the
 // header were then computed over the WHOLE matrix by the caller (block_of_wider = true: no memset, no absmax pass here), so
@@ -578,7 +580,7 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
                                d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
         else     hipLaunchKernelGGL((convert_planar_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
     } else {
-        uint32_t* const dirty = (tiny && gx.pow == 2u && gx.cap) ? hdr : nullptr;   // (SDDMM / fused AGNN at guard level 2: dirty rows for wide_patch_kernel)
+        uint32_t* const dirty = (tiny && (gx.pow & 0xffu) == 2u && gx.cap) ? hdr : nullptr;   // (SDDMM / fused AGNN at guard level 2: dirty rows for wide_patch_kernel)
         if (vec) hipLaunchKernelGGL((convert_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny, dirty);
         else     hipLaunchKernelGGL((convert_kernel<false>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad, pitch, x16, hdr, d_gate, ldx, tiny, dirty);
     }
@@ -1235,14 +1237,14 @@ int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream_v) {
 }
 
 int tcgnn_set_range_guard(int32_t level) {
-    if (level < 0 || level > 2) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_range_guard: 0 (off), 1 (SpMM operators, default) or 2 (every operator)");
+    if (level < 0 || level > 3) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_range_guard: 0 (off), 1 (SpMM operators), 2 (+ SDDMM / fused AGNN with a few lost elements, default) or 3 (strict)");
     g_range_guard = level;
     return TCGNN_OK;
 }
 
 int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, int32_t* wide_val) {
     if (!d_workspace || !wide_x) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_range_mode: null argument");
-    uint32_t h[9];
+    uint32_t h[10];
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     HIP_TRY(hipMemcpyAsync(h, d_workspace, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1255,7 +1257,7 @@ int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, i
     int ex = 0, ea = 0;
     const bool sx = spread(0, ex), sa = spread(1, ea);
     *wide_x = (sx && h[4] != 0u && h[6] != 0u && (int)h[7] * (ex - 127) >= 29 - clog2(std::min(h[4], h[6]))) ? 1 : 0;
-    if (*wide_x && h[7] == 2u && h[8] <= kSparseRows) *wide_x = 2;   // (SDDMM / fused AGNN with a few dirty rows: the MFMA kernel + wide_patch_kernel)
+    if (*wide_x && h[7] == 2u) *wide_x = h[8] <= kSparseRows ? 2 : (h[9] ? 1 : 0);   // (SDDMM / fused AGNN: a few dirty rows - MFMA kernel + wide_patch_kernel; many - fp32 only at the strict level)
     if (wide_val) {
         const uint32_t k = (sa || h[6] >= h[5]) ? h[5] : std::max(h[6], 1u);
         *wide_val = ((sx || sa) && h[5] != 0u && h[0] != 0u && h[1] != 0u && (ex - 127) + (ea - 127) >= 28 - clog2(k)) ? 1 : 0;

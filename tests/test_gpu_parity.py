@@ -1222,7 +1222,7 @@ def _wide_range_body(dev, T):
     assert T.plan_info(*meta)["wide_blocks"] > 8192
     n, D = len(rp) - 1, 64
     rng = np.random.default_rng(11)
-    T.set_range_guard(2)                                      # every operator (the default level guards the SpMM operators only)
+    T.set_range_guard(3)                                      # strict: every operator, whatever the number of lost elements
     att = rng.standard_normal(len(col)).astype(np.float32)
     # (third case, ADVICE r03: an outlier 2^40 above the rest converts everything else to EXACTLY zero - nothing subnormal is left in
     #  the image to count, so the count must come from the source values; before that fix n_tiny was 0 and the call stayed on MFMA)
@@ -1312,6 +1312,9 @@ def _wide_range_body(dev, T):
     T.forward(torch.from_numpy(X).to(dev), *meta)
     assert T.range_mode()[0] == 1
     T.forward_ef(torch.from_numpy(X).to(dev), *meta)          # level 1: SDDMM answers to its documented bound
+    assert T.range_mode()[0] == 0
+    T.set_range_guard(2)                                      # the default: a few dirty rows are patched (the test below), a matrix that is
+    T.forward_ef(torch.from_numpy(X).to(dev), *meta)          # wide all over - 3 999 dirty rows here - stays on the MFMA path as documented
     assert T.range_mode()[0] == 0
     T.clear_plan_cache()
 
