@@ -22,9 +22,6 @@ res = {}
 for rnd in range(rounds):
     for val in ("0", "1"):
         os.environ[var] = val
-        if var == "TCGNN_AGNN_STATE":     # (read at import by tcgnn_layers: set the module switch)
-            import tcgnn_layers as L
-            L.USE_STATE_AGNN = val != "0"
         if var == "RANGE_GUARD":          # (process-wide level, not an environment switch after start-up: 0 -> level 1, 1 -> level 2)
             TCGNN.set_range_guard(1 + int(val))
         for model in ("gcn", "agnn"):
