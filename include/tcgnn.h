@@ -294,23 +294,6 @@ int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* 
                         const uint32_t* d_ef_absmax, float* d_G, float* d_dw, int32_t D,
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* The same pair with the edge weights kept INSIDE the layer (r04).  gnn_conv.py:115-158 hands edge_feature / edge_attentions from
- * forward_ef to forward_AGNN and, saved, to the backward pass - [E]-sized tensors in CSR order that only the layer itself reads.
- * Where the plan has the LDS-resident walks (dense graphs, whole 64-column chunks up to 128 columns, canonical CSR) the weights can
- * stay in the order those walks consume them: forward writes them into an opaque `state` buffer, backward reads them back.
- *   tcgnn_agnn_state_bytes    bytes of `state` for this plan and width, 0 = not available (use tcgnn_agnn_forward / _backward).
- *                             The first call for a plan builds the walk's stream (synchronises `stream`; returns 0 inside a graph
- *                             capture) and raises what tcgnn_workspace_bytes reports for the width.
- *   tcgnn_agnn_state_forward  Y = A_att X, att[e] = fl32(w <X[row e], X[col e]>) as tcgnn_agnn_forward; att -> state (256-aligned)
- *   tcgnn_agnn_state_backward G = A_att dY with the state's att; *d_dw = sum_e <dY[row e], dY[col e]> (float)col(e)
- * Same operand rounding and fp32 accumulation as the other entry points (sums in another order); a matrix the fp16 image cannot
- * hold (range guard, level >= 2) is computed in plain fp32 by one kernel on the same stream. */
-size_t tcgnn_agnn_state_bytes(tcgnn_plan* plan, int32_t D, void* stream);
-int tcgnn_agnn_state_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, void* d_state, size_t state_bytes, float* d_Y,
-                             int32_t D, void* d_workspace, size_t workspace_bytes, void* stream);
-int tcgnn_agnn_state_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const void* d_state, size_t state_bytes,
-                              float* d_G, float* d_dw, int32_t D, void* d_workspace, size_t workspace_bytes, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -478,60 +478,3 @@ def agnn_fused_backward(d_output, nodePointer, edgeList, attention_w, ef, ef_abs
 
 backward = forward        # TCGNN.cpp:270
 backward_ef = forward_ef  # TCGNN.cpp:271
-
-
-# ---------------------------------------------------------------- the fused pair with its edge weights kept inside the layer (r04)
-
-def agnn_state_supported(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
-    """True where tcgnn_agnn_state_forward / _backward cover this graph and width (dense graphs the LDS-resident walks are chosen
-    for, 64 or 128 columns, canonical CSR).  The first call for a graph builds the walk's stream (synchronises)."""
-    if not (input.is_cuda and input.dtype == torch.float32 and input.dim() == 2):
-        return False
-    dev = input.device
-    with torch.cuda.device(dev):
-        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
-        return _c.lib.tcgnn_agnn_state_bytes(plan, input.shape[1], _stream_handle(dev)) > 0
-
-
-def agnn_state_forward(input, nodePointer, edgeList, attention_w, blockPartition, edgeToColumn, edgeToRow):
-    """[Y, state]: Y = forward_AGNN(input, attention_w * forward_ef(input)) (gnn_conv.py:125-132) with the edge weights left in an
-    opaque device buffer - the order the LDS-resident walks consume them in - for agnn_state_backward."""
-    _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
-    dev = input.device
-    _weight_scalar(attention_w, dev)
-    N, D = input.shape
-    out = torch.empty_like(input)
-    with torch.cuda.device(dev):
-        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
-        nbytes = _c.lib.tcgnn_agnn_state_bytes(plan, D, _stream_handle(dev))
-        if nbytes == 0:
-            raise RuntimeError("agnn_state_forward: this graph / width has no state walk (agnn_state_supported)")
-        state = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-        off = (-state.data_ptr()) % 256
-        ws, ws_bytes = _workspace(plan, D, dev)
-        st = _c.lib.tcgnn_agnn_state_forward(plan, input.data_ptr(), attention_w.data_ptr(), state.data_ptr() + off, nbytes, out.data_ptr(), D, ws, ws_bytes,
-                                             _stream_handle(dev))
-    _c.check(st, "tcgnn_agnn_state_forward")
-    return [out, state]
-
-
-def agnn_state_backward(d_output, nodePointer, edgeList, attention_w, state, blockPartition, edgeToColumn, edgeToRow):
-    """[G, d_w] with G = forward_AGNN(d_output, saved edge weights) and d_w = <forward_ef(d_output), edgeList.float()> (gnn_conv.py:143,
-    :150-153) from the state agnn_state_forward left."""
-    _six(d_output, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
-    dev = d_output.device
-    _weight_scalar(attention_w, dev)
-    if state.dtype != torch.uint8 or not state.is_cuda:
-        raise RuntimeError("state is not what agnn_state_forward returned")
-    N, D = d_output.shape
-    out = torch.empty_like(d_output)
-    d_w = torch.empty(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
-        off = (-state.data_ptr()) % 256
-        ws, ws_bytes = _workspace(plan, D, dev)
-        st = _c.lib.tcgnn_agnn_state_backward(plan, d_output.data_ptr(), attention_w.data_ptr(), state.data_ptr() + off, state.numel() - 256, out.data_ptr(),
-                                              d_w.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
-    _c.check(st, "tcgnn_agnn_state_backward")
-    return [out, d_w]
-

@@ -34,7 +34,6 @@
 //   tcgnn_lds_spmm.inc        LDS-resident SpMM, ordinary cell stream; cell-stream build kernels
 //   tcgnn_lds_flat.inc        LDS-resident SpMM, flat cell stream (the headline kernel)
 //   tcgnn_lds_val.inc         LDS-resident edge-valued SpMM (single-edge stream, per-call slot values)
-//   tcgnn_lds_sddmm.inc       the fused AGNN pair on that stream: score walk, combine, the plain-fp32 way (state API)
 //   tcgnn_sddmm.inc           sddmm_kernel, sddmm_wide_kernel
 //   tcgnn_agnn.inc            agnn_kernel (fused pair, forward / backward), slice sum, d_w reduction
 //   tcgnn_small_fallback.inc  spmm_small_kernel, CSR kernels of non-canonical plans, the range guard's fallbacks, wide_patch_kernel
@@ -125,7 +124,6 @@ struct tcgnn_plan {
         int32_t* d_cold_eidx = nullptr;    // [cold_tiles][32]                                                                          (build time only)
         uint16_t* d_eidx16 = nullptr;      // the same as offsets from the window's first CSR edge, 0xffff: none (what val_permute_kernel reads)
         uint16_t* d_cold_eidx16 = nullptr;
-        uint32_t* d_slotinfo = nullptr;    // [tiles][32] row offset in the range | window row << 16 | valid << 31 (the score walk, tcgnn_lds_sddmm.inc)
     };
     CellStream lds[7];   // (kLdsStreams; slot 6: the single-edge stream of the edge-valued LDS-resident SpMM, tcgnn_lds_val.inc)
     // single-edge tile stream (built with slot 6, on the first edge-valued call that would use it): every condensed column repeated
@@ -321,7 +319,6 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
 #include "tcgnn_lds_spmm.inc"
 #include "tcgnn_lds_flat.inc"
 #include "tcgnn_lds_val.inc"
-#include "tcgnn_lds_sddmm.inc"
 
 #include "tcgnn_sddmm.inc"
 
@@ -576,8 +573,7 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
     if (planar) {   // [dpad / 16 planes][Nc + 1][16 halves] for the LDS-resident range kernel (same chunk count: no pitch padding)
         if (vec && D % 16 == 0 && (!d_gate || (reinterpret_cast<uintptr_t>(d_gate) & 15) == 0)) {
             const int64_t threads = ((int64_t)plan->Nc + 1) * (D / 4);
-            hipLaunchKernelGGL(convert_planar_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_X, plan->Nc, D, x16, hdr, d_gate, tiny,
-                               (tiny && (gx.pow & 0xffu) == 2u && gx.cap) ? hdr : (uint32_t*)nullptr);
+            hipLaunchKernelGGL(convert_planar_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_X, plan->Nc, D, x16, hdr, d_gate, tiny);
         } else if (vec) hipLaunchKernelGGL((convert_planar_kernel<true>), dim3(cgrid), dim3(256), 0, stream, d_X, plan->Nc, D, dpad / 16, x16, hdr, d_gate, tiny);
         else if ((size_t)D * 64 * sizeof(float) <= 48 * 1024)
             hipLaunchKernelGGL(convert_planar_tiled_kernel, dim3((unsigned)(((int64_t)plan->Nc + 1 + 63) / 64)), dim3(256), (size_t)D * 64 * sizeof(float), stream,
@@ -766,10 +762,10 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals);
             HIP_TRY(hipGetLastError());
         }
-        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist, 0};
+        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist};
         HIP_TRY(launch_lds_val(va, dpad / 32, stream));
         if (cs.cold_tiles > 0) {
-            const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad, 0};
+            const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad};
             hipLaunchKernelGGL(spmm_cold_val_kernel, dim3((unsigned)((plan->nw_eff + 3) / 4), (unsigned)((dpad + 63) / 64)), dim3(256), 0, stream, ca);
             HIP_TRY(hipGetLastError());
         }
@@ -989,100 +985,6 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     return TCGNN_OK;
 }
 
-// ---- the fused AGNN pair with its edge weights kept in STREAM ORDER between the two products and between forward and backward
-//      (tcgnn_lds_sddmm.inc).  state = 256-byte header (word 0: bit pattern of the bound the values are scaled by) + the slot values
-//      of the single-edge stream + those of its cold tiles.
-static bool agnn_state_ok(const tcgnn_plan* plan, int32_t D) {
-    const int dp = round_up(D, 16);
-    return plan && plan->canonical && plan->nw_eff > 0 && plan->Nc == plan->N && plan->row_off == 0 && plan->E >= 8 && D % 16 == 0 && dp % 64 == 0 && dp <= kMaxChunkDims &&
-           (int64_t)(dp / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32) && (g_spmm_mode == 3 || (g_spmm_mode == 0 && lds_chosen(plan, dp)));
-}
-static size_t agnn_state_bytes(const tcgnn_plan* plan) {
-    const tcgnn_plan::CellStream& cs = plan->lds[kLdsValSlot];
-    return 256 + ((size_t)(std::max<int64_t>(cs.tiles, 1) + std::max<int64_t>(cs.cold_tiles, 0)) * 64 + 255) / 256 * 256;
-}
-// scratch behind the planar image: the passes' partial scores (forward) / the per-wavefront d_w sums (backward)
-static size_t agnn_state_scratch(const tcgnn_plan* plan, int32_t D) {
-    const tcgnn_plan::CellStream& cs = plan->lds[kLdsValSlot];
-    if (plan->val_choice.load(std::memory_order_acquire) != 1 || !cs.d_slotinfo) return 0;
-    const size_t chunks = (size_t)round_up(D, 16) / 32;
-    const size_t part = chunks * (size_t)std::max<int64_t>(cs.tiles, 1) * 32 * sizeof(float);
-    const size_t dw = (chunks * (size_t)cs.nwg * kLdsWaves + (size_t)cs.nwg * kLdsWaves * kLdsMaxW2 + (size_t)plan->nw_eff + 8) * sizeof(double);
-    return (std::max(part, dw) + 255) / 256 * 256;
-}
-static int run_agnn_state(const tcgnn_plan* plan, const float* d_X, const float* d_w, void* d_state, size_t state_bytes, float* d_Y, float* d_dw, int32_t D,
-                          void* ws, size_t ws_bytes, void* stream_v, bool bwd) {
-    const char* name = bwd ? "tcgnn_agnn_state_backward" : "tcgnn_agnn_state_forward";
-    if (!plan || !d_X || !d_w || !d_state || !d_Y || (bwd && !d_dw)) return fail(TCGNN_ERR_INVALID_ARG, "%s: null argument", name);
-    if (!agnn_state_ok(plan, D) || plan->val_choice.load(std::memory_order_acquire) != 1 || !plan->lds[kLdsValSlot].d_slotinfo)
-        return fail(TCGNN_ERR_UNSUPPORTED, "%s: this plan / width has no state walk (tcgnn_agnn_state_bytes says 0): use tcgnn_agnn_forward / _backward", name);
-    const tcgnn_plan::CellStream& cs = plan->lds[kLdsValSlot];
-    if (state_bytes < agnn_state_bytes(plan) || (reinterpret_cast<uintptr_t>(d_state) & 255)) return fail(TCGNN_ERR_WORKSPACE, "%s: state needs %zu bytes, 256-aligned", name, agnn_state_bytes(plan));
-    const size_t image = workspace_bytes_for(plan->Nc, D), scratch = agnn_state_scratch(plan, D);
-    if (!ws || ws_bytes < image + scratch) return fail(TCGNN_ERR_WORKSPACE, "%s: workspace needs %zu bytes, got %zu", name, image + scratch, ws_bytes);
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const Guard gsd = guard_sddmm(D);
-    const int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, true, nullptr, 0, false, nullptr, &gsd);
-    if (rc) return rc;
-    uint32_t* const whdr = const_cast<uint32_t*>(hdr);
-    uint32_t* const shdr = static_cast<uint32_t*>(d_state);
-    _Float16* const vals = reinterpret_cast<_Float16*>(static_cast<char*>(d_state) + 256);
-    _Float16* const cvals = vals + (size_t)std::max<int64_t>(cs.tiles, 1) * 32;
-    char* const sc = static_cast<char*>(ws) + image;
-    const int nchunks = dpad / 32;
-    const int64_t nslots = std::max<int64_t>(cs.tiles, 1) * 32;
-    const bool cold = cs.cold_tiles > 0;
-    const unsigned cgrid = (unsigned)((plan->nw_eff + 3) / 4);
-    KernelTimer timer(plan, stream, bwd ? "spmm_lds_val_kernel + sddmm_lds_kernel<reduce> (state walk)" : "sddmm_lds_kernel + att_combine_kernel + spmm_lds_val_kernel (state walk)");
-    const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist, 1};
-    const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad, 1};
-    if (!bwd) {
-        float* const part = reinterpret_cast<float*>(sc);
-        const SddmmLdsArgs sa{cs.d_slotinfo, cs.d_order, x16, hdr, part, nullptr, nslots, plan->N, dpad / 16, plan->Nc + 1, cs.nwg, cs.d_rbase, cs.d_rlist};
-        HIP_TRY(launch_sddmm_lds<false>(sa, nchunks, stream));
-        hipLaunchKernelGGL(att_combine_kernel, dim3(2048), dim3(256), 0, stream, part, nslots, nchunks, nslots, d_w, whdr, D, vals, shdr);
-        if (cold) hipLaunchKernelGGL(sddmm_cold_kernel, dim3(cgrid), dim3(256), 0, stream, cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, x16, hdr, d_w, plan->N, dpad / 16, plan->Nc + 1,
-                                     plan->nw_eff, cvals, (double*)nullptr, 0);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(launch_lds_val(va, dpad / 32, stream));
-        if (cold) hipLaunchKernelGGL(spmm_cold_val_kernel, dim3(cgrid, (unsigned)((dpad + 63) / 64)), dim3(256), 0, stream, ca);
-        HIP_TRY(hipGetLastError());
-    } else {
-        // the scale the state's values carry -> header word 1, where the aggregation kernels look for it
-        HIP_TRY(hipMemcpyAsync(whdr + 1, shdr, sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(launch_lds_val(va, dpad / 32, stream));
-        if (cold) hipLaunchKernelGGL(spmm_cold_val_kernel, dim3(cgrid, (unsigned)((dpad + 63) / 64)), dim3(256), 0, stream, ca);
-        double* const dwp = reinterpret_cast<double*>(sc);
-        const int n1 = nchunks * cs.nwg * kLdsWaves;
-        const int n2 = cold ? (int)cgrid * 4 : 0;
-        const SddmmLdsArgs sa{cs.d_slotinfo, cs.d_order, x16, hdr, nullptr, dwp, 0, plan->N, dpad / 16, plan->Nc + 1, cs.nwg, cs.d_rbase, cs.d_rlist};
-        HIP_TRY(hipMemsetAsync(dwp, 0, (size_t)(n1 + n2) * sizeof(double), stream));   // (a call that takes the fp32 way leaves these untouched)
-        HIP_TRY(launch_sddmm_lds<true>(sa, nchunks, stream));
-        if (cold) hipLaunchKernelGGL(sddmm_cold_kernel, dim3(cgrid), dim3(256), 0, stream, cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, x16, hdr, d_w, plan->N, dpad / 16, plan->Nc + 1,
-                                     plan->nw_eff, (_Float16*)nullptr, dwp + n1, 1);
-        HIP_TRY(hipGetLastError());
-    }
-    // the plain-fp32 way (returns at once unless the staged matrix is wide; then the kernels above returned at once)
-    {
-        const int nslots_w = cs.nwg * kLdsWaves * kLdsMaxW2;
-        double* const dww = bwd ? reinterpret_cast<double*>(sc) + (size_t)nchunks * cs.nwg * kLdsWaves + (cold ? (size_t)cgrid * 4 : 0) : nullptr;
-        if (bwd) HIP_TRY(hipMemsetAsync(dww, 0, (size_t)nslots_w * sizeof(double), stream));
-        const StateWideArgs wa{cs.d_slotinfo, cs.d_order, cs.d_rbase, cs.d_rlist, cold ? cs.d_cold_ptr : nullptr, cs.d_cold_cols, cs.d_cold_mask, d_X, d_w, whdr, shdr,
-                               vals, cvals, d_Y, dww, plan->N, D, cs.nwg, lds_stream_buf_rows(kLdsValSlot) - 8};
-        const size_t lds = (size_t)4 * 16 * D * sizeof(float);
-        if (bwd) hipLaunchKernelGGL((agnn_state_wide_kernel<true>), dim3((unsigned)(nslots_w / 4)), dim3(256), lds, stream, wa);
-        else hipLaunchKernelGGL((agnn_state_wide_kernel<false>), dim3((unsigned)(nslots_w / 4)), dim3(256), lds, stream, wa);
-        HIP_TRY(hipGetLastError());
-        if (bwd) {
-            const int ntot = nchunks * cs.nwg * kLdsWaves + (cold ? (int)cgrid * 4 : 0) + nslots_w;
-            hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, reinterpret_cast<const double*>(sc), ntot, d_dw, (const double*)nullptr);
-            HIP_TRY(hipGetLastError());
-        }
-    }
-    return TCGNN_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -1100,26 +1002,6 @@ int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* 
     return run_agnn(plan, d_dY, d_w, const_cast<float*>(d_ef), const_cast<uint32_t*>(d_ef_absmax), d_G, d_dw, D, ws, ws_bytes, stream, true);
 }
 
-size_t tcgnn_agnn_state_bytes(tcgnn_plan* plan, int32_t D, void* stream_v) {
-    if (!agnn_state_ok(plan, D)) return 0;
-    if (plan->val_choice.load(std::memory_order_acquire) < 0) {
-        hipStream_t stream = static_cast<hipStream_t>(stream_v);
-        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return 0;
-        if (build_val_stream(plan, stream) != TCGNN_OK) return 0;
-    }
-    if (plan->val_choice.load(std::memory_order_acquire) != 1 || !plan->lds[kLdsValSlot].d_slotinfo) return 0;
-    return agnn_state_bytes(plan);
-}
-int tcgnn_agnn_state_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, void* d_state, size_t state_bytes, float* d_Y, int32_t D,
-                             void* ws, size_t ws_bytes, void* stream) {
-    return run_agnn_state(plan, d_X, d_w, d_state, state_bytes, d_Y, nullptr, D, ws, ws_bytes, stream, false);
-}
-int tcgnn_agnn_state_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const void* d_state, size_t state_bytes, float* d_G, float* d_dw, int32_t D,
-                              void* ws, size_t ws_bytes, void* stream) {
-    return run_agnn_state(plan, d_dY, d_w, const_cast<void*>(d_state), state_bytes, d_G, d_dw, D, ws, ws_bytes, stream, true);
-}
-
 int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
@@ -1127,7 +1009,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
-        (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold); (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); (void)hipFree(cs.d_eidx16); (void)hipFree(cs.d_cold_eidx16); (void)hipFree(cs.d_slotinfo);
+        (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold); (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); (void)hipFree(cs.d_eidx16); (void)hipFree(cs.d_cold_eidx16);
     }
     (void)hipFree(plan->d_xwb_ptr); (void)hipFree(plan->d_xcols); (void)hipFree(plan->d_xmask); (void)hipFree(plan->d_xeidx);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
@@ -1439,8 +1321,7 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     }
     // (the edge-valued LDS-resident walk keeps its per-call slot values behind the image, once its stream exists: tcgnn_lds_val.inc)
     const size_t vals = (round_up(D, 16) % 64 == 0 && round_up(D, 16) <= 2 * kMaxChunkDims) ? val_stream_bytes(plan) : (size_t)0;
-    const size_t state = agnn_state_ok(plan, D) ? agnn_state_scratch(plan, D) : (size_t)0;   // (the fused pair's state walk: partial scores behind the image)
-    return image + std::max({agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D), two_images ? image : (size_t)0, vals, state});
+    return image + std::max({agnn_partial_bytes(plan) + agnn_slice_bytes(plan, D), two_images ? image : (size_t)0, vals});
 }
 
 int tcgnn_spmm(const tcgnn_plan* plan, const float* d_X, float* d_Y, int32_t D, void* ws, size_t ws_bytes, void* stream) {

@@ -29,7 +29,6 @@ import torch.nn.functional as F
 
 n_heads = 1  # gnn_conv.py:10
 USE_FUSED_AGNN = True  # tests switch it off to compare with the separate calls
-USE_STATE_AGNN = os.environ.get("TCGNN_AGNN_STATE", "1") != "0"   # the fused pair's state walk (TCGNN.agnn_state_*) where the plan has it
 
 _backend = None
 
@@ -328,14 +327,6 @@ class TCGNNFunction_AGNN(torch.autograd.Function):
         ctx.meta = meta
         ctx.fused = bool(USE_FUSED_AGNN and attention_w.numel() == 1 and hasattr(b, "agnn_fused_forward")
                          and b.agnn_fused_supported(H, *meta))
-        # r04: where the LDS-resident walks cover the graph the edge weights stay inside the layer, in the order those walks read
-        # them (TCGNN.agnn_state_*): no [E]-sized score tensor in CSR order between the two products or for the backward pass
-        ctx.state = bool(ctx.fused and USE_STATE_AGNN and hasattr(b, "agnn_state_forward") and b.agnn_state_supported(H, *meta))
-        if ctx.state:
-            w1 = attention_w.detach().reshape(1).contiguous()
-            out, state = b.agnn_state_forward(H, row_pointers, column_index, w1, blockPartition, edgeToColumn, edgeToRow)
-            ctx.save_for_backward(X, weights, w1, state)
-            return out
         if ctx.fused:
             w1 = attention_w.detach().reshape(1).contiguous()
             out, ef, ef_absmax = b.agnn_fused_forward(H, row_pointers, column_index, w1, blockPartition, edgeToColumn, edgeToRow)
@@ -354,11 +345,7 @@ class TCGNNFunction_AGNN(torch.autograd.Function):
         row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow = ctx.meta
         d_output = d_output.contiguous()
         b = backend()
-        if getattr(ctx, "state", False):
-            X, weights, w1, state = ctx.saved_tensors
-            g, d_w = b.agnn_state_backward(d_output, row_pointers, column_index, w1, state, blockPartition, edgeToColumn, edgeToRow)
-            d_attention_w = d_w.reshape(1, n_heads)
-        elif ctx.fused:
+        if ctx.fused:
             X, weights, w1, ef, ef_absmax = ctx.saved_tensors
             g, d_w = b.agnn_fused_backward(d_output, row_pointers, column_index, w1, ef, ef_absmax, blockPartition, edgeToColumn, edgeToRow)
             d_attention_w = d_w.reshape(1, n_heads)

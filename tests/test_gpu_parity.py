@@ -679,68 +679,6 @@ def test_edge_valued_spmm_on_the_lds_resident_walk(dev, T, D, shape, monkeypatch
     assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
 
 
-@pytest.mark.parametrize("shape", ["dense", "denser", "multi_edge_columns", "ragged"])
-@pytest.mark.parametrize("D", [64, 128])
-def test_fused_agnn_state_walk_equals_the_gather_pair_and_the_oracle(dev, T, D, shape, monkeypatch):
-    """r04: the fused AGNN pair with its edge weights kept in stream order (tcgnn_lds_sddmm.inc:
-    sddmm_lds_kernel + att_combine_kernel + spmm_lds_val_kernel forward; the aggregation and a reduced score walk backward).
-    Forced (mode 3, one tile per cell: most of these graphs is cold remainder) against the oracle's two operators, fp64 and the
-    gather pair: Y, G, d_w; deterministic."""
-    import tcgnn_capi as c
-    if shape == "dense":
-        rp, col = graphs.uniform_graph(4100, 150, seed=21)
-    elif shape == "denser":
-        rp, col = graphs.uniform_graph(3000, 400, seed=23)
-    elif shape == "multi_edge_columns":
-        rp, col = graphs.uniform_graph(1000, 500, seed=25)
-    else:
-        rp, col = graphs.uniform_graph(2061, 120, seed=24)      # N % 16 = 13
-    n, nnz = len(rp) - 1, len(col)
-    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
-    rng = np.random.default_rng(D + 31)
-    X = (rng.standard_normal((n, D)) / D ** 0.25).astype(np.float32)
-    dY = rng.standard_normal((n, D)).astype(np.float32)
-    tX, tdY = to_dev(dev, X, dY)
-    w = np.float32(0.6)
-    tw = torch.tensor([w], device=dev)
-    monkeypatch.setenv("TCGNN_LDS_FLAT", "1")
-    T.clear_plan_cache()
-    try:
-        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
-        assert T.agnn_state_supported(tX, *meta)
-        Y, state = T.agnn_state_forward(tX, meta[0], meta[1], tw, *meta[2:])
-        kf = T.last_kernel(*meta)
-        Y2, state2 = T.agnn_state_forward(tX, meta[0], meta[1], tw, *meta[2:])
-        G, dw = T.agnn_state_backward(tdY, meta[0], meta[1], tw, state, *meta[2:])
-        kb = T.last_kernel(*meta)
-        G2, dw2 = T.agnn_state_backward(tdY, meta[0], meta[1], tw, state2, *meta[2:])
-        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
-        Yg, ef_g, efm = T.agnn_fused_forward(tX, meta[0], meta[1], tw, *meta[2:])
-        Gg, dwg = T.agnn_fused_backward(tdY, meta[0], meta[1], tw, ef_g, efm, *meta[2:])
-    finally:
-        c.lib.tcgnn_set_spmm_mode(0)
-        T.clear_plan_cache()
-    assert "state walk" in kf and "state walk" in kb, (kf, kb)
-    assert torch.equal(Y, Y2) and torch.equal(G, G2) and torch.equal(dw, dw2)      # deterministic (the state buffers hold unwritten padding: not compared)
-    ef = O.sddmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
-    att = (w * ef).astype(np.float32)
-    refY = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32); Y64, aY = O.spmm_f64(X, rp, col, att)
-    # (an edge weight one accumulation-noise step away can round to the neighbouring 10-bit value: 2^-11 of the term, hence 256 x TIGHT)
-    assert (np.abs(Y.cpu().numpy() - refY) / (aY + 1.0)).max() <= 256 * TIGHT
-    assert (np.abs(Y.cpu().numpy() - Y64) / (aY + 1.0)).max() <= 2.0 ** -9
-    # (the 1e-3 max(1, |ref|) bar is asserted where the aggregate can be checked on the kernel's OWN scores - the gather pair's tests;
-    #  here the scores stay inside the state, and a neighbouring 10-bit weight on a cancelling row sum alone is worth ~1e-3 of it)
-    refG = O.spmm_val(dY, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, aG = O.spmm_f64(dY, rp, col, att)
-    assert (np.abs(G.cpu().numpy() - refG) / (aG + 1.0)).max() <= 256 * TIGHT
-    d_att = O.sddmm(dY, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, ad = O.sddmm_f64(dY, rp, col)
-    want_dw = float((d_att.astype(np.float64) * col.astype(np.float64)).sum())
-    assert abs(float(dw) - want_dw) <= 1e-5 * (float((ad * col).sum()) + 1.0), (float(dw), want_dw)
-    # ... and the gather pair says the same
-    assert (np.abs(Y.cpu().numpy() - Yg.cpu().numpy()) / (aY + 1.0)).max() <= 256 * TIGHT
-    assert (np.abs(G.cpu().numpy() - Gg.cpu().numpy()) / (aG + 1.0)).max() <= 256 * TIGHT
-    assert abs(float(dw) - float(dwg)) <= 1e-5 * (float((ad * col).sum()) + 1.0)
-
-
 @pytest.mark.parametrize("D", [16, 41, 64, 96, 128])   # (128: what the backward pass takes on the Reddit shape since r03; 96: the old row layout)
 def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatch):
     """r03: the XCD-sliced walk of the fused kernel (workgroup b gathers only rows of column slice b % 8, so an XCD's L2 holds the
