@@ -98,7 +98,7 @@ def pmc_workload(shape, gen, D):
 def main():
     import tcgnn_capi
     bid = tcgnn_capi.build_id()
-    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra", "--no-cpu", "--steps", "100", "--warmup", "5"]   # (100 steps: the average over ALL launches of the process is the steady state's, not the first dozen slow launches')
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra", "--no-cpu", "--steps", "100", "--warmup", "5"]   # (100 steps: the average over ALL launches of the process is the steady state's, not the first dozen slow launches)
     stats(bench, "bench_spmm_reddit_d64")
     try:   # the line printed under the profiler, next to the profiler's own average
         line = [l for l in open(os.path.join(OUT, "bench_spmm_reddit_d64.log")) if l.startswith("{")][-1]
