@@ -9,7 +9,7 @@ import TCGNN, tcgnn_graph as G, tcgnn_capi as c
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
 n, nnz, _, _ = G.SHAPES["reddit"]
-rp, col = G.synthetic_csr(n, nnz, seed=0, device=dev)
+rp, col = G.GENERATORS[os.environ.get("GEN", "uniform")](n, nnz, seed=0, device=dev)   # GEN=uniform|rmat|sbm|sbm_reddit ...
 E = col.numel(); nw = (n + 15) // 16
 bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
 fd = os.open(os.devnull, os.O_WRONLY); sv = os.dup(1); os.dup2(fd, 1)
@@ -19,7 +19,9 @@ meta = (rp, col, bp, e2c, e2r)
 X = torch.randn(n, D, device=dev)
 c.lib.tcgnn_set_spmm_mode(3)
 TCGNN.forward(X, *meta); TCGNN.kernel_timing(*meta, max_calls=10)
-for _ in range(10): TCGNN.forward(X, *meta)
+for _ in range(int(os.environ.get("WARM", "10"))): TCGNN.forward(X, *meta)
+TCGNN.kernel_timing(*meta)
+for _ in range(30): TCGNN.forward(X, *meta)
 t = TCGNN.kernel_timing(*meta)
 if int(os.environ.get("TCGNN_LDS_DBG", "0")) & 16:
     y = TCGNN.forward(X, *meta)[0].flatten()[:128].cpu().numpy()
