@@ -613,7 +613,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
     if (!d_val && !d_staged && !d_W && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
-        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, nullptr};
+        const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, plan->nw_eff, nullptr};
         KernelTimer timer(plan, stream, "spmm_small_kernel");
         hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
         HIP_TRY(hipGetLastError());
@@ -740,8 +740,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)plan->N + 3) / 4, 4096);
         if (d_W) hipLaunchKernelGGL(spmm_gemm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, plan->rowptr, plan->col, d_X, d_W, d_Y, plan->N, D, D_out, relu);
         else if (!d_val && ld == D) {   // binary A, whole rows: the fp32-MFMA walk small graphs take anyway (10-bit operands, fp32's exponent)
-            const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, hdr};
-            hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)plan->nw_eff, (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
+            const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, plan->nw_eff, hdr};
+            hipLaunchKernelGGL(spmm_small_kernel, dim3((unsigned)std::min(plan->nw_eff, 2048), (unsigned)((D + 63) / 64)), dim3(64), 0, stream, sa);
         }
         else hipLaunchKernelGGL(spmm_wide_fallback_kernel, dim3(grid), dim3(256), 0, stream, hdr, d_val ? 1 : 0, plan->rowptr, plan->col, d_val, (const float*)nullptr, d_X, d_gate, d_Y,
                                 plan->N, D, (int64_t)ld, (int64_t)ld, relu, (!d_val && !plan->canonical) ? 1 : 0);
