@@ -316,6 +316,7 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
 #include "tcgnn_gather_spmm.inc"
 
 
+#include "tcgnn_small_spmm.inc"
 #include "tcgnn_lds_spmm.inc"
 #include "tcgnn_lds_flat.inc"
 #include "tcgnn_lds_val.inc"
@@ -815,6 +816,9 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (rc) return rc;
         }
         const tcgnn_plan::CellStream& cs0 = plan->lds[lds_stream_of(passes[0].nt, passes[0].maxw)];
+        // one launch, binary A, whole rows, nothing added behind it: the kernel is its own range-guard fallback (lds_own_fallback)
+        const bool own_fb = npass == 1 && !cold && !d_W && !d_staged && ld == D && !(cs0.flat_tpc && cs0.cold_tiles > 0 && !cs0.d_wcold_ptr);
+        const SpmmSmallArgs fb{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, plan->nw_eff, own_fb ? hdr : nullptr};
         KernelTimer timer(plan, stream, cold ? "spmm_lds_kernel + spmm_kernel (cold remainder)" :
                                         (cs0.flat_tpc ? (cs0.cold_tiles > 0 && !cs0.d_wcold_ptr ? "spmm_lds_flat_kernel + spmm_cold_planar_kernel (cold remainder)" : "spmm_lds_flat_kernel") : "spmm_lds_kernel"));
         for (int i = 0; i < npass; ++i) {
@@ -822,7 +826,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (cs.flat_tpc) {
                 const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
-                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold};
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
                 HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
@@ -834,7 +838,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                 continue;
             }
             SpmmLdsArgs l{cs.d_cell_ptr, cs.d_cell_tiles, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1,
-                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_parts};
+                          cs.nranges, plan->nw_eff, cs.nwg, g_lds_dbg, cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, cs.d_parts, fb};
             HIP_TRY(launch_lds_any(passes[i].maxw, passes[i].nt, l, passes[i].nchunks, stream));
         }
         if (cold) {
@@ -850,7 +854,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (rem) { a.chunk0 = nfull; HIP_TRY(launch_spmm_any(false, waves, rem, a, plan->nw_eff, 1, stream)); }
         }
         timer.stop();
-        return wide_fallback();
+        return own_fb ? TCGNN_OK : wide_fallback();
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
                image_is_big(plan->Nc, pitch), d_W, D_out, 0};

@@ -1081,6 +1081,42 @@ def test_range_robustness_beyond_fp16(dev, T):
     assert not Z.any()
 
 
+@pytest.mark.parametrize("flat", [0, 1])
+def test_lds_resident_kernels_are_their_own_range_guard_fallback(dev, T, flat, monkeypatch):
+    """r04: behind the LDS-resident binary SpMM the guard's fp32 fallback used to be a launch of its own - a gate that returns at once
+    and costs 4.5 us of every aggregation.  spmm_lds_kernel / spmm_lds_flat_kernel now run that walk themselves when the staged
+    matrix is wide (lds_own_fallback): forced here (mode 3; the flat stream on a small graph by TCGNN_LDS_FLAT), a 3e7 row over
+    1e-3 data, N % 16 != 0, D = 64 (one launch) and 80 (two passes: the fallback stays a launch of its own), with a ReLU; against
+    the oracle.  The same call on ordinary data stays on the MFMA kernel."""
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(4109, 100, seed=31)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    n = len(rp) - 1
+    rng = np.random.default_rng(3 + flat)
+    monkeypatch.setenv("TCGNN_LDS_FLAT", str(flat))
+    T.clear_plan_cache()
+    try:
+        c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+        for D in (64, 80):
+            for wide in (True, False):
+                X = (rng.standard_normal((n, D)) * (1e-3 if wide else 1.0)).astype(np.float32)
+                if wide:
+                    X[777] = 3e7 * (1.0 + rng.random(D).astype(np.float32))
+                Y = T.forward(torch.from_numpy(X).to(dev), *meta)[0].cpu().numpy()
+                kernel = T.last_kernel(*meta)
+                assert kernel.startswith("spmm_lds_flat_kernel" if flat else "spmm_lds_kernel"), kernel
+                assert T.range_mode()[0] == (1 if wide else 0)
+                ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+                r64, a64 = O.spmm_f64(X, rp, col)
+                assert_parity(Y, ref, r64, a64, "D=%d wide=%s flat=%d" % (D, wide, flat), unit_scale=not wide)
+                if wide:   # rows that never touch the outlier are what the fp16 image loses: they must be there, to accumulation accuracy
+                    small = a64.max(axis=1) < 1.0
+                    assert small.sum() > n // 2 and np.abs(Y[small] - r64[small]).max() <= 2.0 ** -9 * a64[small].max() and np.abs(Y[small]).max() > 0
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+
+
 def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
     try:
         _wide_range_body(dev, T)
