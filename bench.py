@@ -51,6 +51,13 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+GRAPH_NOTES = {
+    "uniform": "seeded uniform symmetric, canonical CSR",
+    "sbm_reddit": "seeded 50-community SBM calibrated to real Reddit's TC-block count (22.5 % of the edges inside a community; "
+                  "tcgnn_graph.SBM_REDDIT_P_IN), symmetric, canonical CSR",
+    "rmat": "seeded R-MAT 0.57/0.19/0.19/0.05, symmetric, canonical CSR",
+    "sbm": "seeded 50-community SBM, 90 % of the edges inside a community, symmetric, canonical CSR",
+}
 
 
 def parse():
@@ -60,6 +67,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--dim", type=int, default=64, help="hidden width D of the timed SpMM")
     p.add_argument("--shape", type=str, default="reddit")
+    p.add_argument("--graph", type=str, default="sbm_reddit",
+                   help="generator of the headline graph (tcgnn_graph.GENERATORS).  Default since r05: sbm_reddit, the 50-community graph "
+                        "calibrated to real Reddit's TC-block count (13.63 M 16x8 blocks against 13.57 M, /root/reference/logs/reduce_blocks.csv:18); "
+                        "r01-r04 reported the uniform graph, whose figures stay in `summary` (uniform_*)")
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; the reported config is scale 1)")
     p.add_argument("--epochs", type=int, default=10, help="timed epochs of the GCN / AGNN legs")
     p.add_argument("--no-extra", action="store_true", help="skip SDDMM / epoch / CPU legs (profiling runs)")
@@ -299,7 +310,7 @@ def single_gpu(args):
             sys.stderr.write("bench: %s found but not loaded (%s); measuring the synthetic graph of the same shape\n" % (real, str(exc)[:200]))
             real = None
     if not real:
-        rp_d, col_d = G.synthetic_csr(n, nnz_target, seed=args.seed, device=dev)
+        rp_d, col_d = G.GENERATORS[args.graph](n, nnz_target, seed=args.seed, device=dev)
     torch.cuda.synchronize()
     gen_s = time.perf_counter() - t0
     E = col_d.numel()
@@ -342,6 +353,7 @@ def single_gpu(args):
     kernel_ms = kernel_ms_all[-args.steps:]                                  # the K timed steps
     TCGNN.kernel_timing(*meta, max_calls=0)
     k_mean = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    k_all = float(np.mean(kernel_ms_all)) if kernel_ms_all else k_mean
     ms_per_step = elapsed * 1e3 / args.steps
     gteps = E / (elapsed / args.steps) / 1e9
     workload = "%s N=%d nnz=%d, SpMM D=%d (GCN aggregation, fwd = bwd)" % (args.shape + ("-shape synthetic graph" if data == "synthetic" else " (real graph)"), n, E, D)
@@ -355,13 +367,16 @@ def single_gpu(args):
         "value_all_launches": round(E / ((float(np.mean(kernel_ms_all)) + (ms_per_step - k_mean)) * 1e-3) / 1e9, 3) if kernel_ms_all else None,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 x f16 -> f32 (MFMA), f32 I/O", "data": data,
-        "config": {"workload": workload, "graph": "seeded uniform symmetric, canonical CSR" if data == "synthetic" else data, "tc_blocks_16x8": info["tc_blocks"],
+        "config": {"workload": workload, "graph": GRAPH_NOTES.get(args.graph, args.graph) if data == "synthetic" else data, "tc_blocks_16x8": info["tc_blocks"],
                    "reddit_real_tc_blocks_16x8": 13566510, "wide_blocks_16x32": info["wide_blocks"],
                    "waves_per_window": info["waves_per_window"], "lds_column_ranges": info.get("lds_ranges", 0), "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": kname,
-                     "achieved": round(roof_b / (k_mean * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5),
-                     **profile_fields(kname, "%s_uniform_d%d" % (args.shape.replace("ogbn-", ""), D), 2.0 * E * D, k_mean),
+                     # (`achieved` / `frac` over EVERY launch of the process - settle + warm-up + timed - the population a
+                     #  profiler's per-kernel average covers; the K timed, post-settle launches alone are `frac_steady`)
+                     "achieved": round(roof_b / (k_all * 1e-3) / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(roof_b / (k_all * 1e-3) / HBM_PEAK, 5),
+                     "frac_steady": round(roof_b / (k_mean * 1e-3) / HBM_PEAK, 5),
+                     **profile_fields(kname, "%s_%s_d%d" % (args.shape.replace("ogbn-", ""), args.graph, D), 2.0 * E * D, k_mean),
                      "algorithmic_bytes": roof_b, "kernel_ms_mean": round(k_mean, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4) if kernel_ms else None,
                      "kernel_launches_timed": len(kernel_ms),
                      # every launch of the process (settle + W + K): the population a profiler's per-kernel average covers
@@ -516,7 +531,7 @@ def single_gpu(args):
     # ---- per-dataset list (north star: "MFMA utilisation and HBM GB/s ... on each dataset"): the headline graph, the same shape
     #      from the R-MAT and community generators (condensing and cache behaviour depend on locality), and
     #      BASELINE.json configs[3], ogbn-products AGNN hidden = 128
-    datasets = [{"dataset": "%s shape, uniform generator (headline)" % args.shape, "workload": "%s_uniform_d%d" % (args.shape.replace("ogbn-", ""), D),
+    datasets = [{"dataset": "%s shape, %s generator (headline)" % (args.shape, args.graph), "workload": "%s_%s_d%d" % (args.shape.replace("ogbn-", ""), args.graph, D),
                  "N": n, "nnz": int(E), "D": D, "tc_blocks_16x8": info["tc_blocks"],
                  "spmm": {"kernel": kname, "kernel_ms": round(k_mean, 4), "gteps": round(gteps, 3), "hbm_frac": out["roofline"]["frac"],
                           **{k: out["roofline"][k] for k in ("traffic", "mfma_busy", "mfma_useful_frac", "mfma_useful_tflops", "mfma_peak_frac")}}}]
@@ -526,7 +541,9 @@ def single_gpu(args):
         # (the three generators SURVEY.md 8d names, plus the community graph calibrated to real Reddit's TC-block count -
         #  tcgnn_graph.SBM_REDDIT_P_IN; the hub / shuffled / relabelled variants of r02 are behind --all-generators)
         more = ((args.shape, "sbm_hubs", D, every), (args.shape, "sbm_shuffled", D, every), (args.shape, "sbm_shuffled+reorder", D, every + ("gcn_epoch", "agnn_epoch"))) if args.all_generators else ()
-        for shape, gen, d, ops in ((args.shape, "sbm_reddit", D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")),
+        # (the headline graph is args.graph - measured above; the uniform graph r01-r04 reported takes its place in this list)
+        second = "uniform" if args.graph != "uniform" else "sbm_reddit"
+        for shape, gen, d, ops in ((args.shape, second, D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")),
                                    (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")), *more,
                                    ("ogbn-products", "uniform", 128, every + ("gcn_epoch", "agnn_epoch")),
                                    ("ogbn-products", "sbm", 128, every),
@@ -799,9 +816,14 @@ def plan_only(args):
         acts = 4 * rows_r * (2 * D + 2 * classes) * 2                     # X W, A(X W) per layer, and their gradients
         image_w = 256 + (ncols + 1) * x16_pitch_halves((widest + 15) // 16 * 16) * 2
         total = csr + sgt + plan + image_w + gather_all + feats + acts
-        out_rows.append({"rank": r, "rows": rows_r, "edges": nnz_r, "gathered_rows": ncols, "csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan,
-                         "image_fp16_bytes": image, "gather_buffer_bytes": gather, "features_bytes": feats, "layer_tensors_bytes": acts,
-                         "total_bytes": total, "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES})
+        # (the listed parts are the ones summed - the image of the WIDEST layer and the gather buffers of BOTH widths;
+        #  the hidden-width figures ride along under *_hidden_only and are not part of the sum)
+        parts = {"csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan, "image_fp16_widest_layer_bytes": image_w,
+                 "gather_buffers_all_widths_bytes": gather_all, "features_bytes": feats, "layer_tensors_bytes": acts}
+        assert sum(parts.values()) == total
+        out_rows.append({"rank": r, "rows": rows_r, "edges": nnz_r, "gathered_rows": ncols, **parts,
+                         "image_fp16_hidden_only_bytes": image, "gather_buffer_hidden_only_bytes": gather,
+                         "total_bytes": total, "parts_summed": sorted(parts), "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES})
     H = per[0][2]
     blk32, blk16 = 4 * H * D, 2 * H * x16_pitch_halves((D + 15) // 16 * 16)
     doc = {"plan_only": True, "workload": "%s GCN hidden=%d, rows sharded over %d GPUs (BASELINE.json configs[4])" % (shape, D, world),
@@ -877,8 +899,14 @@ def compact_line(out, limit=LINE_LIMIT):
             summary += [("sbm_reddit_spmm_ms", row["spmm"].get("kernel_ms")), ("sbm_reddit_spmm_frac", row["spmm"].get("hbm_frac")),
                         ("sbm_reddit_spmm_kernel", clip(row["spmm"].get("kernel"), 40)), ("sbm_reddit_tc_blocks_16x8", row.get("tc_blocks_16x8")),
                         ("sbm_reddit_gcn_ms_per_epoch", row.get("gcn_ms_per_epoch")), ("sbm_reddit_agnn_ms_per_epoch", row.get("agnn_ms_per_epoch"))]
+        if isinstance(row, dict) and row.get("workload", "").endswith("_uniform_d%s" % (D or "")) and isinstance(row.get("spmm"), dict) and "(headline)" not in row.get("dataset", ""):
+            # the graph r01-r04 reported as the headline: kept for continuity
+            summary += [("uniform_spmm_ms", row["spmm"].get("kernel_ms")), ("uniform_spmm_gteps", row["spmm"].get("gteps")), ("uniform_spmm_frac", row["spmm"].get("hbm_frac")),
+                        ("uniform_spmm_kernel", clip(row["spmm"].get("kernel"), 40)), ("uniform_sddmm_ms", _leg(row.get("sddmm"))), ("uniform_spmm_agnn_ms", _leg(row.get("spmm_val"))),
+                        ("uniform_agnn_fused_fwd_ms", _leg(row.get("agnn_fused_fwd"))), ("uniform_agnn_fused_bwd_ms", _leg(row.get("agnn_fused_bwd"))),
+                        ("uniform_gcn_ms_per_epoch", row.get("gcn_ms_per_epoch")), ("uniform_agnn_ms_per_epoch", row.get("agnn_ms_per_epoch"))]
         if isinstance(row, dict) and row.get("workload", "").endswith("_rmat_d%s" % (D or "")) and isinstance(row.get("spmm"), dict):
-            summary += [("rmat_spmm_ms", row["spmm"].get("kernel_ms"))]
+            summary += [("rmat_spmm_ms", row["spmm"].get("kernel_ms")), ("rmat_spmm_agnn_ms", _leg(row.get("spmm_val")))]
         if isinstance(row, dict) and row.get("workload") == "products_uniform_d128":
             summary += [("products_d128_%s_ms" % op, _leg(row.get(op))) for op in ("spmm", "sddmm", "spmm_val")]
             summary += [("products_d128_sddmm_frac", _leg(row.get("sddmm"), "hbm_frac")), ("products_agnn_h128_ms_per_epoch", row.get("agnn_ms_per_epoch")),

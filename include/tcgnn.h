@@ -39,8 +39,8 @@
  *     bits) of them for an SpMM, min(2 D, that number) for SDDMM and the fused AGNN pair - could leave the contract's
  *     1e-3 max(1, |ref|): max|X| >= 2^29 / k (binary SpMM), max|A| max|X| >= 2^28 / k (edge-valued), max|X|^2 >= 2^29 / k
  *     (SDDMM, fused AGNN).  A training epoch's activations (one stray 1e-5 among 1e4's) stay on the MFMA path.  Images the
- *     CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path (the call
- *     clears the reserved header words itself).
+ *     CALLER stages (tcgnn_spmm_staged) carry no range words and always take the MFMA path (the kernels
+ *     do not look at the rest of such a header).
  *   - Index arrays are int32 (the reference API's dtype); all address arithmetic inside the
  *     kernels is 64-bit, so N*D may exceed 2^32 (the reference overflows there,
  *     TCGNN_kernel.cu:420).
@@ -159,6 +159,12 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
  * LDS-resident kernel where the plan's time model picks it for that width; nothing for the gather walks).  Synchronises
  * `stream`.  Idempotent; widths are independent.  No counterpart in the reference (its kernels re-derive their tiles per launch). */
 int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream);
+/* The same for the EDGE-VALUED SpMM (tcgnn_spmm_val = TCGNN.forward_AGNN, gnn_conv.py:132,143): builds the single-edge cell stream of the
+ * LDS-resident edge-valued walk where the plan takes that walk at width D (whole 64-column chunks on graphs the time model sends to
+ * the LDS-resident kernel; nothing otherwise).  Call it BEFORE tcgnn_workspace_bytes: the answer then includes the per-call slot
+ * values, and the first tcgnn_spmm_val of that width neither allocates nor synchronises nor takes the gather walk.  Synchronises
+ * `stream`.  Idempotent. */
+int tcgnn_plan_prepare_val(tcgnn_plan* plan, int32_t D, void* stream);
 int tcgnn_plan_destroy(tcgnn_plan* plan);
 int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
 
@@ -172,6 +178,9 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * (no staging pass; binary SpMM only).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
  * initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
+/* The same switch for ONE plan: mode 0 .. 4 as above, -1 = follow the process-wide value (the default).  Two plans of one process may
+ * walk differently. */
+int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode);
 
 /* The range guard (see "Operand range" above), process-wide level (environment TCGNN_RANGE_GUARD sets the initial one):
  *   0  off - every call stays on the MFMA path;
@@ -182,15 +191,18 @@ int tcgnn_set_spmm_mode(int32_t mode);
  *      ONE element 2^28 below) cross that bound now and then.  Such a matrix has a handful of "dirty" rows: the MFMA kernels run
  *      as usual and one more launch recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch them
  *      (scores, their share of the aggregate and of d_w) - ~0.1 ms when it happens, a launch that returns at once when it does
- *      not.  A matrix with MORE than 48 such rows (hub rows of a power-law graph under unscaled weights: the range is wide all
+ *      not.  Dirty rows are counted once per row (a row cut by a wavefront boundary of the conversion pass may count twice).  A matrix
+ *      with MORE than 48 such rows (hub rows of a power-law graph under unscaled weights: the range is wide all
  *      over) stays on the MFMA path at this level and answers to the bound as documented;
  *   3  strict: such a matrix too is computed in plain fp32, CSR order (correct for any magnitudes, ~50x slower than the MFMA
  *      path on a Reddit-sized graph).
  * tcgnn_range_mode reports which way the LAST staged call on this workspace went: *wide_x = 1 if its feature matrix took the fp32
  * fallback as a binary SpMM / SDDMM / fused AGNN operand, 2 if it stayed on the MFMA path with its dirty rows patched (SDDMM /
- * fused AGNN), *wide_val (optional) = 1 if it took the fallback as an edge-valued SpMM.  Reads 36 bytes of the workspace header
+ * fused AGNN), *wide_val (optional) = 1 if it took the fallback as an edge-valued SpMM.  Reads 40 bytes of the workspace header
  * back: synchronises `stream` (a test / diagnosis aid, like tcgnn_plan_last_kernel - the hot path never reads anything back). */
 int tcgnn_set_range_guard(int32_t level);
+/* The guard level of ONE plan: 0 .. 3 as above, -1 = follow the process-wide level (the default). */
+int tcgnn_plan_set_range_guard(tcgnn_plan* plan, int32_t level);
 int tcgnn_range_mode(const void* d_workspace, void* stream, int32_t* wide_x, int32_t* wide_val);
 
 /* Measurement aid: reserve HIP event pairs for up to `max_calls` kernel calls (0 = off).  While
@@ -250,8 +262,8 @@ int tcgnn_spmm_gemm(const tcgnn_plan* plan, const float* d_X, const float* d_W, 
  *   tcgnn_stage_rows   : `rows` rows of X -> rows + 1 image rows at d_dst (the extra row is zero), scaled by *d_absmax_word
  *                        exactly as tcgnn_spmm would;
  *   tcgnn_spmm_staged  : Y = A_bin * X from such an image (gather walks; results identical to tcgnn_spmm on the same walk).
- *                        Header words 1 .. 7 (bytes 4 .. 31) are RESERVED for the range guard and are cleared by the call on
- *                        `stream` (a staged image is never "wide"); bytes 32 .. 255 are ignored.  The image is otherwise read-only. */
+ *                        Only word 0 of the header is read (a staged image is never "wide": bytes 4 .. 255 are ignored and may hold
+ *                        anything).  The image is READ-ONLY to the call: one image may feed several streams or ranks at once. */
 int tcgnn_x16_pitch(int32_t D);
 int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream);
 int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, void* stream);

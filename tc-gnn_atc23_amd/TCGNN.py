@@ -159,16 +159,29 @@ def plan_info(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
     return {f: getattr(info, f) for f, _ in info._fields_}
 
 
-def prepare(widths, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow):
+def prepare(widths, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, edge_valued=False):
     """Not part of the reference API: build, now, what the hot path would otherwise build at its first call of each feature width
-    in `widths` (tcgnn_plan_prepare: the cell streams of the LDS-resident kernel where the plan's time model picks it).  After it
-    no forward / backward call of those widths synchronises or allocates inside the library, and a call captured into a HIP graph
-    takes the walk it would take outside one.  The harness calls it with the model's widths before the dry epochs."""
+    in `widths` (tcgnn_plan_prepare: the cell streams of the LDS-resident kernel where the plan's time model picks it; with
+    edge_valued=True also tcgnn_plan_prepare_val: the single-edge stream forward_AGNN's LDS-resident walk reads).  After it no
+    forward / backward (/ forward_AGNN) call of those widths synchronises or allocates inside the library, and a call captured into
+    a HIP graph takes the walk it would take outside one.  The harness calls it with the model's widths before the dry epochs."""
     plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
     dev = nodePointer.device
     with torch.cuda.device(dev):
         for d in sorted({int(w) for w in widths if int(w) >= 1}):
             _c.check(_c.lib.tcgnn_plan_prepare(plan, d, _stream_handle(dev)), "tcgnn_plan_prepare")
+            if edge_valued:
+                _c.check(_c.lib.tcgnn_plan_prepare_val(plan, d, _stream_handle(dev)), "tcgnn_plan_prepare_val")
+
+
+def set_plan_modes(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, spmm_mode=None, range_guard=None):
+    """Not part of the reference API: the walk (tcgnn_plan_set_spmm_mode) and the range-guard level (tcgnn_plan_set_range_guard) of
+    THIS graph's plan only; -1 hands a setting back to the process-wide value.  Two graphs of one process may differ."""
+    plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
+    if spmm_mode is not None:
+        _c.check(_c.lib.tcgnn_plan_set_spmm_mode(plan, int(spmm_mode)), "tcgnn_plan_set_spmm_mode")
+    if range_guard is not None:
+        _c.check(_c.lib.tcgnn_plan_set_range_guard(plan, int(range_guard)), "tcgnn_plan_set_range_guard")
 
 
 def range_mode(device=None):

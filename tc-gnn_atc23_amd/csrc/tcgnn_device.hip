@@ -141,6 +141,9 @@ struct tcgnn_plan {
     mutable std::vector<hipEvent_t> ev;
     mutable std::atomic<int> ev_used{0};
     mutable std::atomic<const char*> last_kernel{""};   // name of the main kernel the last call launched (tcgnn_plan_last_kernel)
+    // per-plan overrides of the process-wide switches (tcgnn_plan_set_spmm_mode / tcgnn_plan_set_range_guard; -1: follow the process-wide
+    // value of tcgnn_set_spmm_mode / tcgnn_set_range_guard) - two plans of one process may differ
+    std::atomic<int8_t> spmm_mode{-1}, range_guard{-1};
     std::vector<int32_t> h_bp;       // blockPartition on the host: window weights for the placement of the LDS-resident walks
     mutable std::atomic<int> lds_extra[2] = {{-1}, {-1}};   // window slots the split hub windows add (4 / 8 windows per wavefront); -1: not computed
 };
@@ -231,8 +234,17 @@ __device__ __forceinline__ bool wide2_sparse(const uint32_t* hdr) { return range
 //  work in plain fp32; at the default level the call stays on the MFMA path and answers to the documented bound, like level 1)
 __device__ __forceinline__ bool wide2_dense(const uint32_t* hdr) { return range_is_wide(hdr, 0) && hdr[8] > kSparseRows && hdr[9] != 0u; }
 // conversion pass: a thread that met an element losing bits records the row (duplicates are possible: the patch de-duplicates)
+// (once per ROW - a row's 8-element chunks sit in consecutive lanes, and only the first lane of a wavefront that met a lost
+//  element of the row records it; a row cut by a wavefront boundary may still be recorded twice, which the patch de-duplicates, so the
+//  documented limit of 48 dirty rows is no longer reached by six fully tiny rows of 64 columns)
 __device__ __forceinline__ void note_dirty_row(uint32_t* hdr, uint32_t nt, int64_t row) {
-    if (!hdr || !nt) return;
+    if (!hdr) return;   // (wave-uniform)
+    const uint64_t dirty = __ballot(nt != 0u);
+    const int lane = (int)(threadIdx.x & 63);
+    const uint64_t below = dirty & ((1ull << lane) - 1ull);
+    const int prev = below ? 63 - __clzll((long long)below) : lane;
+    const int prev_row = __shfl((int)row, prev);   // (row numbers fit 31 bits; executed by every active lane)
+    if (!nt || (below && prev_row == (int)row)) return;
     const uint32_t k = atomicAdd(hdr + 8, 1u);
     if (k < kSparseRows) hdr[16 + k] = (uint32_t)row;
 }
@@ -424,6 +436,7 @@ static constexpr int g_lds_dbg = 0;
 #endif
 static constexpr int g_lds_fill_quota = 1;     // (r03: the wavefronts with an empty last slot take the range fills, -0.5 %)
 static int g_spmm_mode = [] { const char* e = getenv("TCGNN_SPMM_MODE"); return e ? atoi(e) : 0; }();
+static inline int spmm_mode_of(const tcgnn_plan* p) { const int m = p ? (int)p->spmm_mode.load(std::memory_order_relaxed) : -1; return m >= 0 ? m : g_spmm_mode; }
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr size_t kBlockedMinBytes = 6u << 20;   // below this X16 is (nearly) L2-resident anyway
 static constexpr size_t kRangeTargetBytes = 1u << 20;  // X16 bytes per column range: wavefronts drift by a range or two
@@ -530,13 +543,14 @@ static size_t agnn_slice_bytes(const tcgnn_plan* plan, int32_t D) {
 // of the graph (SpMM) or 2 D (SDDMM / fused AGNN) - and the power of max|X| in the error bound.  cap 0 = guard off
 // (tcgnn_set_range_guard(0), TCGNN_RANGE_GUARD=0).
 static int g_range_guard = [] { const char* e = getenv("TCGNN_RANGE_GUARD"); return e ? atoi(e) : 2; }();   // (r04: 2 - the usual wide input of SDDMM / fused AGNN costs one patch launch; 3 = strict)
+static inline int range_guard_of(const tcgnn_plan* p) { const int g = p ? (int)p->range_guard.load(std::memory_order_relaxed) : -1; return g >= 0 ? g : g_range_guard; }
 struct Guard { uint32_t cap, pow; };
-static Guard guard_spmm(const tcgnn_plan* p) { return {g_range_guard ? (uint32_t)std::max(p->max_degree, 1) : 0u, 1u}; }
+static Guard guard_spmm(const tcgnn_plan* p) { return {range_guard_of(p) ? (uint32_t)std::max(p->max_degree, 1) : 0u, 1u}; }
 // (level 1, the default: the aggregation operators - binary and edge-valued SpMM, the fused dense update - whose bound is linear in
 //  max|X| and which a training epoch never reaches; level 2 adds SDDMM and the fused AGNN pair, whose bound is QUADRATIC in max|X|:
 //  an AGNN epoch of the reference's unscaled recipe crosses 2^14.5 with a single lost element now and then, and each such call
 //  costs ~25 ms in the CSR fallbacks against 2 ms - so those two answer to the documented bound unless asked to be strict)
-static Guard guard_sddmm(int D) { return {g_range_guard >= 2 ? (uint32_t)(2 * std::max(D, 1)) : 0u, 2u | (g_range_guard >= 3 ? 0x100u : 0u)}; }   // (bit 8: strict, header word 9)
+static Guard guard_sddmm(const tcgnn_plan* p, int D) { const int lv = range_guard_of(p); return {lv >= 2 ? (uint32_t)(2 * std::max(D, 1)) : 0u, 2u | (lv >= 3 ? 0x100u : 0u)}; }   // (bit 8: strict, header word 9)
 
 // ldx > 0: X (and the gate) is a column block of a wider row-major matrix with that row stride; the scale words in the
 // header were then computed over the WHOLE matrix by the caller (block_of_wider = true: no memset, no absmax pass here), so
@@ -597,6 +611,10 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 static constexpr int kMaxGatherBlockDims = 4096;
 
 static bool agnn_supported(const tcgnn_plan* plan, int32_t D);
+// widths the LDS-resident edge-valued walk covers: whole 64-column chunks of a canonical plan whose planar image one descriptor addresses
+static bool val_lds_width_ok(const tcgnn_plan* plan, int dp) {
+    return dp % 64 == 0 && dp <= 2 * kMaxChunkDims && plan->canonical && plan->nw_eff > 0 && (int64_t)(dp / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32);
+}
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
                     void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr,
                     int64_t ld = 0, bool block_of_wider = false, const float* d_W = nullptr, int32_t D_out = 0) {
@@ -612,7 +630,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         HIP_TRY(hipGetLastError());
         return TCGNN_OK;
     }
-    const int mode = g_spmm_mode; // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
+    const int mode = spmm_mode_of(plan); // 0 auto, 1 plain, 2 blocked, 3 LDS-resident ranges, 4 single-launch fp32 kernel
     if (!d_val && !d_staged && !d_W && plan->nw_eff > 0 && (mode == 4 || (mode == 0 && plan->total_wb <= kSmallMaxTiles))) {
         const SpmmSmallArgs sa{plan->d_wb_ptr, plan->d_cols, plan->d_mask, d_X, d_gate, d_Y, plan->N, plan->Nc, D, relu, plan->nw_eff, nullptr};
         KernelTimer timer(plan, stream, "spmm_small_kernel");
@@ -712,13 +730,15 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     bool val_lds = false;
     {
         const int dp = round_up(D, 16);
-        if (d_val && !d_staged && !block_of_wider && !d_gate && !relu && !d_W && (mode == 0 || mode == 3) && dp % 64 == 0 && dp <= 2 * kMaxChunkDims && plan->canonical &&
-            plan->nw_eff > 0 && (int64_t)(dp / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32) && (mode == 3 || lds_chosen(plan, dp))) {
+        if (d_val && !d_staged && !block_of_wider && !d_gate && !relu && !d_W && (mode == 0 || mode == 3) && val_lds_width_ok(plan, dp) && (mode == 3 || lds_chosen(plan, dp))) {
             if (plan->val_choice.load(std::memory_order_acquire) < 0) {
                 hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
                 if (!(hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)) {
+                    // (the stream is an optional acceleration - in automatic mode a failed build, e.g. no memory for its 0.9 GB
+                    //  of temporaries, settles the plan on the gather walks, as the binary path does; only the forced mode reports it)
                     const int b = build_val_stream(const_cast<tcgnn_plan*>(plan), stream);
-                    if (b) return b;
+                    if (b && mode == 3) return b;
+                    if (b) const_cast<tcgnn_plan*>(plan)->val_choice.store(0, std::memory_order_release);
                 }
             }
             val_lds = plan->val_choice.load(std::memory_order_acquire) == 1 && ws_bytes >= workspace_bytes_for(plan->Nc, D) + val_stream_bytes(plan);
@@ -845,7 +865,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             const int pitch_r = x16_pitch(dpad);
             // (the per-tile metadata DMA fetches 16 edge-offset words too; binary SpMM never looks at them: the mask array stands in)
             SpmmArgs a{cold->d_cold_ptr, plan->d_order, cold->d_cold_cols, cold->d_cold_mask, reinterpret_cast<const int32_t*>(cold->d_cold_mask), x16_rows, nullptr, hdr, d_Y, plan->N, D, pitch_r, 0, plan->E,
-                       plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1};
+                       plan->Nc + 1, relu, (int32_t)D, image_is_big(plan->Nc, pitch_r), nullptr, 0, 1, 0};
             constexpr int cold_w4 = 48;   // tiles per window from which 4 wavefronts share it (SBM Reddit shape, 25 cold tiles per window: 169 us with one wavefront, 202 with four)
             // (and a window with hundreds of cold tiles - a hub - is 0.25 us per tile of serial work for one wavefront)
             const int waves = (cold->cold_tiles >= (int64_t)cold_w4 * plan->nw_eff || cold->cold_max >= 512) ? 4 : 1;
@@ -857,7 +877,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         return own_fb ? TCGNN_OK : wide_fallback();
     }
     SpmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, d_val, hdr, d_Y, plan->N, D, pitch, 0, plan->E, plan->Nc + 1, relu, (int32_t)ld,
-               image_is_big(plan->Nc, pitch), d_W, D_out, 0};
+               image_is_big(plan->Nc, pitch), d_W, D_out, 0, d_staged ? 1 : 0};
     if (d_W) a.ldy = D_out;
     const int nfull = dpad / kMaxChunkDims, rem = (dpad % kMaxChunkDims) / 16;
     // range-blocked walk when the fp16 image of X overflows L2 and the windows are long enough to cut
@@ -920,7 +940,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     if (!bwd) HIP_TRY(hipMemsetAsync(d_absmax, 0, sizeof(uint32_t), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const Guard gsd = guard_sddmm(D);
+    const Guard gsd = guard_sddmm(plan, D);
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D));
@@ -937,7 +957,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     // The range-major variant (bit-compatible scores, sums in another order): slower than the per-window walk while the kernel
     // asked for every 128-byte line twice (r02: D = 64 1.87 vs 1.80 ms forward); with whole-line gathers (r03) its forward pass
     // is the fastest form at D = 64 (1.45-1.48 against 1.74 per-window, 1.53 sliced) - agnn_walk picks it there; mode 2 forces it.
-    const bool blocked = plan->nbuckets > 0 && (g_spmm_mode == 2 || (g_spmm_mode == 0 && walk == kAgnnRangeMajor)) && x16_bytes > 0 && !a.big;
+    const bool blocked = plan->nbuckets > 0 && (spmm_mode_of(plan) == 2 || (spmm_mode_of(plan) == 0 && walk == kAgnnRangeMajor)) && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
     {
         KernelTimer timer(plan, stream, (sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel");
@@ -975,7 +995,8 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     // (the d_w correction of the patch: a double in header words 10-11, zeroed with the header by the staging pass)
     double* const dw_extra = reinterpret_cast<double*>(const_cast<uint32_t*>(hdr) + 10);
-    if (g_range_guard >= 2) {
+    const int guard_level = range_guard_of(plan);
+    if (guard_level >= 2) {
         // a few dirty rows (what training produces): the MFMA kernel above ran, the edges that touch them are recomputed here
         const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, d_w, d_Y, d_absmax, dw_extra, plan->N, plan->Nc, D, plan->row_off, bwd ? 2 : 1, plan->E};
         // (many: the same launch does all the work in plain fp32 - wide_dense_body; one launch per call either way, returning at once
@@ -983,7 +1004,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
         HIP_TRY(launch_wide_patch(pa, stream, partial, nwg));
     }
     if (bwd) {
-        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw, g_range_guard >= 2 ? dw_extra : (const double*)nullptr);
+        hipLaunchKernelGGL(agnn_reduce_kernel, dim3(1), dim3(kReduceThreads), 0, stream, partial, nwg, d_dw, guard_level >= 2 ? dw_extra : (const double*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return TCGNN_OK;
@@ -1226,7 +1247,8 @@ int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream_v) {
     if (!plan || D < 1) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_prepare: null plan or D < 1");
     if (plan->nw_eff <= 0 || plan->N == 0) return TCGNN_OK;
     const int dpad = round_up(D, 16);
-    if (!(g_spmm_mode == 3 || (g_spmm_mode == 0 && plan->total_wb > kSmallMaxTiles && lds_chosen(plan, dpad)))) return TCGNN_OK;   // the gather walks need nothing built
+    const int mode = spmm_mode_of(plan);
+    if (!(mode == 3 || (mode == 0 && plan->total_wb > kSmallMaxTiles && lds_chosen(plan, dpad)))) return TCGNN_OK;   // the gather walks need nothing built
     if ((int64_t)(dpad / 16) * ((int64_t)plan->Nc + 1) * 32 >= ((int64_t)1 << 32)) return TCGNN_OK;
     LdsPass passes[2];
     const int np = lds_passes(dpad, passes);
@@ -1234,9 +1256,37 @@ int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream_v) {
         const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
         if (plan->lds[slot].nranges > 0) continue;
         const int rc = build_lds_cells(plan, static_cast<hipStream_t>(stream_v), slot);
-        if (rc && g_spmm_mode == 3) return rc;
+        if (rc && mode == 3) return rc;
         if (rc && dpad / 16 <= 64) plan->lds_choice[dpad / 16] = 0;   // (as the hot path would: no memory for the stream -> the gather walks)
     }
+    return TCGNN_OK;
+}
+
+// Builds, now, what the first tcgnn_spmm_val call of width D would build inside the hot path: the single-edge cell stream of the
+// LDS-resident edge-valued walk (tcgnn_lds_val.inc) where the plan's time model takes that walk for D.  After it tcgnn_workspace_bytes
+// already includes the slot values, so the FIRST forward_AGNN (gnn_conv.py:132) runs the LDS-resident kernels and neither allocates nor
+// synchronises (VERDICT r04 item 6 ii).
+int tcgnn_plan_prepare_val(tcgnn_plan* plan, int32_t D, void* stream_v) {
+    if (!plan || D < 1) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_prepare_val: null plan or D < 1");
+    if (plan->nw_eff <= 0 || plan->N == 0 || plan->E < 4 || !plan->canonical) return TCGNN_OK;
+    const int dp = round_up(D, 16), mode = spmm_mode_of(plan);
+    if (!((mode == 0 || mode == 3) && val_lds_width_ok(plan, dp) && (mode == 3 || lds_chosen(plan, dp)))) return TCGNN_OK;
+    if (plan->val_choice.load(std::memory_order_acquire) >= 0) return TCGNN_OK;
+    const int b = build_val_stream(plan, static_cast<hipStream_t>(stream_v));
+    if (b && mode == 3) return b;
+    if (b) plan->val_choice.store(0, std::memory_order_release);
+    return TCGNN_OK;
+}
+
+int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode) {
+    if (!plan || mode < -1 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_spmm_mode: null plan, or mode outside -1 (process-wide value) .. 4");
+    plan->spmm_mode.store((int8_t)mode, std::memory_order_relaxed);
+    return TCGNN_OK;
+}
+
+int tcgnn_plan_set_range_guard(tcgnn_plan* plan, int32_t level) {
+    if (!plan || level < -1 || level > 3) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_range_guard: null plan, or level outside -1 (process-wide value) .. 3");
+    plan->range_guard.store((int8_t)level, std::memory_order_relaxed);
     return TCGNN_OK;
 }
 
@@ -1311,7 +1361,7 @@ size_t tcgnn_workspace_bytes(const tcgnn_plan* plan, int32_t D) {
     const size_t image = workspace_bytes_for(plan->Nc, D);
     // (before the width's streams exist the answer is the conservative one; once built, only an ORDINARY stream with a cold
     //  remainder stages the second image - a flat stream's remainder reads the planar one)
-    bool two_images = plan->nw_eff > 0 && (g_spmm_mode == 3 || (g_spmm_mode == 0 && lds_chosen(plan, round_up(D, 16))));
+    bool two_images = plan->nw_eff > 0 && (spmm_mode_of(plan) == 3 || (spmm_mode_of(plan) == 0 && lds_chosen(plan, round_up(D, 16))));
     if (two_images) {
         LdsPass passes[2];
         const int np = lds_passes(round_up(D, 16), passes);
@@ -1376,10 +1426,9 @@ int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* 
 int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream) {
     if (!d_image || (reinterpret_cast<uintptr_t>(d_image) & 255)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_staged: the image must be 256-byte aligned");
     // Every MFMA kernel opens with the range guard's test on header words 2, 4, 6, 7; a caller-staged image carries no range words
-    // (never "wide": there is no fp32 X to fall back to).  The reserved words 1 .. 7 are cleared here, on the caller's stream, so a
-    // header a caller left uninitialised beyond word 0 cannot make the kernels return early with Y unwritten.
-    if (hipMemsetAsync(static_cast<char*>(const_cast<void*>(d_image)) + 4, 0, 28, static_cast<hipStream_t>(stream)) != hipSuccess)
-        return fail(TCGNN_ERR_HIP, "tcgnn_spmm_staged: clearing the reserved header words failed");
+    // (never "wide": there is no fp32 X to fall back to).  The gather walks are told so (SpmmArgs::unguarded) and never look at
+    // bytes 4 .. 255 of the header: the image is READ-ONLY to this call, as the signature says - one staged image may be shared by
+    // several streams or ranks (r04 cleared those words with a memset on the caller's image, a write racing with other readers).
     return run_spmm(plan, nullptr, nullptr, d_Y, D, nullptr, 0, stream, 0, nullptr, d_image);
 }
 
@@ -1400,7 +1449,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     }
     if ((int64_t)plan->nw_eff * kWinRows < plan->N) HIP_TRY(hipMemsetAsync(d_ef, 0, (size_t)plan->E * sizeof(float), stream));
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
-    const Guard gsd = guard_sddmm(D);
+    const Guard gsd = guard_sddmm(plan, D);
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
     SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0};
@@ -1410,7 +1459,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // Range-major walk (bit-identical results).  With the outputs staged per row the loop is bound by the gather again,
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
-    const bool blocked = ks <= 4 && plan->nbuckets > 0 && g_spmm_mode != 1 && (g_spmm_mode == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
+    const bool blocked = ks <= 4 && plan->nbuckets > 0 && spmm_mode_of(plan) != 1 && (spmm_mode_of(plan) == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
     hipError_t e;
     if (blocked) {
         // (r03, whole-line gathers: D = 64 1.26 / 1.24 ms at 4 / 8 MB ranges, 1.36 at 2 MB; D = 128 - an image of 60 MB - 2.33 at 2 MB,
@@ -1441,7 +1490,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     HIP_TRY(e);
     timer.stop();
     // (the range guard's fallback: returns at once unless X is "wide")
-    if (g_range_guard >= 2) {   // a few dirty rows: the patch behind the MFMA kernel; many: the CSR fallback (each returns at once otherwise)
+    if (range_guard_of(plan) >= 2) {   // a few dirty rows: the patch behind the MFMA kernel; many: the CSR fallback (each returns at once otherwise)
         const PatchArgs pa{hdr, plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, nullptr, nullptr, nullptr, nullptr, plan->N, plan->Nc, D, plan->row_off, 0, plan->E};
         HIP_TRY(launch_wide_patch(pa, stream));
     }

@@ -45,6 +45,9 @@ SIGNATURES = {
     "tcgnn_plan_create": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_create_sharded": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i32, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_prepare": (ctypes.c_int, [_vp, _i32, _vp]),
+    "tcgnn_plan_prepare_val": (ctypes.c_int, [_vp, _i32, _vp]),
+    "tcgnn_plan_set_spmm_mode": (ctypes.c_int, [_vp, _i32]),
+    "tcgnn_plan_set_range_guard": (ctypes.c_int, [_vp, _i32]),
     "tcgnn_plan_destroy": (ctypes.c_int, [_vp]),
     "tcgnn_plan_get_info": (ctypes.c_int, [_vp, ctypes.POINTER(PlanInfo)]),
     "tcgnn_set_spmm_mode": (ctypes.c_int, [_i32]),

@@ -98,9 +98,9 @@ def test_plan_only_prints_the_per_rank_memory_plan_of_config_5(tmp_path):
     assert sum(x["rows"] for x in doc["per_rank"]) == doc["nodes"] and sum(x["edges"] for x in doc["per_rank"]) == doc["edges"]
     for x in doc["per_rank"]:
         assert x["edges"] < 2 ** 31 and x["rows"] % 16 == 0 or x["rank"] == 7
-        parts = ("csr_bytes", "sgt_metadata_bytes", "plan_bytes_est", "features_bytes", "layer_tensors_bytes")
-        assert x["total_bytes"] > sum(x[k] for k in parts) and x["total_bytes"] < doc["hbm_bytes_per_gpu"]
-        assert x["image_fp16_bytes"] == 256 + (x["gathered_rows"] + 1) * 128          # D = 64: one 128-byte line per row
+        assert x["total_bytes"] == sum(x[k] for k in x["parts_summed"]) and x["total_bytes"] < doc["hbm_bytes_per_gpu"]   # (the listed parts add up)
+        assert {"csr_bytes", "sgt_metadata_bytes", "plan_bytes_est", "features_bytes", "layer_tensors_bytes"} <= set(x["parts_summed"])
+        assert x["image_fp16_hidden_only_bytes"] == 256 + (x["gathered_rows"] + 1) * 128          # D = 64: one 128-byte line per row
     ex = doc["exchange_per_spmm"]
     assert ex["fp16_block_bytes"] * 2 == ex["fp32_block_bytes"] and 20 < ex["fp32_ms_link_bound"] < 26    # ~23 ms fp32, ~12 ms fp16
     # with shard files: rows and edges per rank are the files'

@@ -203,6 +203,29 @@ def test_device_sgt_is_bit_identical_to_host_sgt(dev, T, capfd):
             assert gbp[len(bp)].item() == -7
 
 
+def test_device_sgt_equals_the_reference_written_fixtures(dev, T, capfd):
+    """The chain device SGT -> reference closes ON the GPU box: tests/golden/sgt_*.npz were written by the reference's own compiled
+    `preprocess` (TCGNN.cpp:172-226 through oracle/_ref, tests/golden/make_golden.py); the device translation must reproduce them
+    bit for bit, the count it prints included (the test above only compares with the product's host SGT)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(GOLD, "sgt_*.npz")))
+    assert len(paths) >= 10
+    for path in paths:
+        f = np.load(path)
+        rp, col = f["rowptr"], f["col"]
+        n = len(rp) - 1
+        nw = (n + 15) // 16
+        trp, tcol = to_dev(dev, rp, col)
+        gbp = torch.full((nw + 2,), -7, dtype=torch.int32, device=dev)
+        ge2c = torch.zeros(max(len(col), 1), dtype=torch.int32, device=dev)
+        ge2r = torch.zeros(max(len(col), 1), dtype=torch.int32, device=dev)
+        assert T.preprocess_gpu(tcol, trp, n, 16, 8, gbp, ge2c, ge2r) is None
+        tc = int(f["tc_blocks"])
+        assert capfd.readouterr().out == "TC_Blocks:\t%d\nExp_Edges:\t%d\n" % (tc, tc * 128), path
+        assert np.array_equal(gbp[:nw].cpu().numpy(), f["bp_with_guard"][:nw]), path
+        assert np.array_equal(ge2c[: len(col)].cpu().numpy(), f["e2c"]) and np.array_equal(ge2r[: len(col)].cpu().numpy(), f["e2r"]), path
+
+
 def test_rows_wider_than_the_descriptor_stride_go_as_column_blocks(dev, T):
     """D > 8128: one fp16 row no longer fits the 14-bit stride field of the gather walks' buffer descriptor (r1 ADVICE: it
     wrapped silently and every gather read the wrong row).  Such calls are cut into 4096-column blocks that share the whole
@@ -677,6 +700,97 @@ def test_edge_valued_spmm_on_the_lds_resident_walk(dev, T, D, shape, monkeypatch
     assert torch.equal(Y, again)                                                     # deterministic
     assert_parity(Y.cpu().numpy(), ref, Y64, absY, "LDS-resident edge-valued walk", unit)
     assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+
+
+def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=31):
+    """forward_AGNN forced onto the LDS-resident edge-valued walk (mode 3 of ONE plan, stream built by prepare) -> (Y, kernel, refs)."""
+    rp, col = graphs.uniform_graph(3000, 200, seed=seed)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(seed)
+    X = (rng.standard_normal((n, 64)) * x_scale).astype(np.float32)
+    att = att_fn(rng, nnz).astype(np.float32)
+    tX, tatt = to_dev(dev, X, att)
+    monkeypatch.setenv("TCGNN_LDS_FLAT", "1")
+    T.clear_plan_cache()
+    try:
+        T.set_plan_modes(*meta, spmm_mode=3)
+        if prepare:
+            T.prepare([64], *meta, edge_valued=True)
+        Y = T.forward_AGNN(tX, meta[0], meta[1], tatt.view(1, -1), *meta[2:])[0].cpu().numpy()
+        kernel = T.last_kernel(*meta)
+    finally:
+        T.clear_plan_cache()
+    ref = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    Y64, absY = O.spmm_f64(X, rp, col, att)
+    return Y, kernel, ref, Y64, absY
+
+
+def test_lds_val_walk_with_a_maximum_that_rounds_up_to_a_power_of_two(dev, T, monkeypatch):
+    """the A fragment used to be 2.0 x value in fp16; a maximum edge value whose mantissa is all ones rounds up to
+    2^15 in the scaled image and 2.0 x 32768 is inf - NaN wherever the feature is 0.  Top mantissa all ones, several binades; the
+    value is now SELECTED by a mask.  Also the first call after tcgnn_plan_prepare_val takes the LDS-resident walk (VERDICT r04 6 ii)."""
+    for k in (-3, 0, 7):
+        def att_fn(rng, nnz, k=k):
+            a = rng.standard_normal(nnz) * 0.1 * 2.0 ** k
+            a[rng.integers(0, nnz, 50)] = np.float32(1.99999) * 2.0 ** k      # rounds (10-bit, ties away) to 2^(k+1)
+            a[0] = -np.float32(1.99999) * 2.0 ** k
+            return a
+        Y, kernel, ref, Y64, absY = _lds_val_case(dev, T, monkeypatch, att_fn)
+        assert "spmm_lds_val_kernel" in kernel, kernel
+        assert np.isfinite(Y).all(), "inf / NaN at k = %d" % k
+        assert_parity(Y, ref, Y64, absY, "max |value| = 1.99999 * 2^%d" % k, False)
+
+
+def test_lds_val_walk_scales_whose_exponents_add_up_beyond_fp32(dev, T, monkeypatch):
+    """kx + ka may reach +-253 - the output scale is two factors, as in the gather walks (both operands tiny /
+    both huge; the products themselves stay representable)."""
+    for xs, vs in ((2.0 ** -60, 2.0 ** -40), (2.0 ** 40, 2.0 ** 50), (2.0 ** -70, 2.0 ** 70)):
+        Y, kernel, ref, Y64, absY = _lds_val_case(dev, T, monkeypatch, lambda rng, nnz, vs=vs: rng.standard_normal(nnz) * vs, x_scale=xs)
+        assert "spmm_lds_val_kernel" in kernel, kernel
+        scale = float(absY.max())
+        assert np.isfinite(Y).all() and scale > 0
+        assert np.abs(Y - Y64).max() <= 2.0 ** -9 * scale, (xs, vs)
+        assert np.abs(Y - ref).max() <= 1e-4 * scale, (xs, vs)
+
+
+def test_two_plans_of_one_process_walk_differently(dev, T):
+    """VERDICT r04 6 iv: spmm_mode and range_guard per plan (tcgnn_plan_set_spmm_mode / _range_guard); the process-wide setters stay
+    the defaults.  Same graph twice (two sets of tensors = two plans): one forced to the per-window gather walk, one to the
+    LDS-resident kernel; and one plan with the guard off while the other keeps the default."""
+    rp, col = graphs.uniform_graph(4000, 100, seed=41)
+    n = len(rp) - 1
+    (bp, e2c, e2r), m1 = meta_for(dev, rp, col)
+    _, m2 = meta_for(dev, rp, col)
+    X = np.random.default_rng(1).standard_normal((n, 64)).astype(np.float32)
+    tX = torch.from_numpy(X).to(dev)
+    T.clear_plan_cache()
+    try:
+        T.set_plan_modes(*m1, spmm_mode=1)
+        T.set_plan_modes(*m2, spmm_mode=3)
+        Y1 = T.forward(tX, *m1)[0]; k1 = T.last_kernel(*m1)
+        Y2 = T.forward(tX, *m2)[0]; k2 = T.last_kernel(*m2)
+        assert k1 == "spmm_kernel" and k2.startswith("spmm_lds"), (k1, k2)
+        ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+        Y64, absY = O.spmm_f64(X, rp, col)
+        assert_parity(Y1.cpu().numpy(), ref, Y64, absY, "plan 1")
+        assert_parity(Y2.cpu().numpy(), ref, Y64, absY, "plan 2")
+        # the guard: a wide matrix (one 3e7 row over 1e-3 data) - plan 1 with the guard off stays on MFMA, plan 2 (default) falls back
+        Xw = (np.random.default_rng(2).standard_normal((n, 64)) * 1e-3).astype(np.float32); Xw[5] = 3e7
+        tXw = torch.from_numpy(Xw).to(dev)
+        T.set_plan_modes(*m1, spmm_mode=-1, range_guard=0)
+        T.set_plan_modes(*m2, spmm_mode=-1)
+        T.forward(tXw, *m1); w1 = T.range_mode()[0]
+        Yw2 = T.forward(tXw, *m2)[0].cpu().numpy(); w2 = T.range_mode()[0]
+        assert w1 == 0 and w2 == 1, (w1, w2)
+        Yw64, absw = O.spmm_f64(Xw, rp, col)
+        has5 = np.zeros(n, bool)
+        has5[np.repeat(np.arange(n), np.diff(rp))[col == 5]] = True
+        small = np.where(~has5)[0]                                       # rows that do not touch the huge row keep their own accuracy
+        assert len(small) > n // 2
+        assert (np.abs(Yw2[small] - Yw64[small]) <= 2.0 ** -9 * (absw[small] + 1e-30)).all()
+    finally:
+        T.clear_plan_cache()
 
 
 @pytest.mark.parametrize("D", [16, 41, 64, 96, 128])   # (128: what the backward pass takes on the Reddit shape since r03; 96: the old row layout)
