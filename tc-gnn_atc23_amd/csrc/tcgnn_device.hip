@@ -102,6 +102,10 @@ struct tcgnn_plan {
         int32_t npairs = 0;
         int32_t* d_rbase = nullptr;        // [nwg + 1]
         int32_t* d_rlist = nullptr;        // [npairs + 4]
+        // flat streams: the workgroup's walk as a list of ENTRIES (tcgnn_lds_flat.inc) - npairs and rbase then count entries, and
+        // d_rl2 [entries][16 wavefronts][2] holds the entry words (range | dense flag, next range / per-slot tile counts)
+        uint32_t* d_rl2 = nullptr;
+        int32_t dense_entries = 0;
         // cold remainder: columns of the (workgroup, range) pairs too thin for a range fill, re-condensed per window in the gather
         // walks' packed format; run by spmm_kernel, ADDING into what the LDS-resident kernel stored
         int64_t cold_tiles = 0, hot_cols = 0, cold_cols = 0, cold_max = 0;   // cold_max: cold tiles of the longest window
@@ -783,7 +787,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals);
             HIP_TRY(hipGetLastError());
         }
-        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rlist};
+        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rl2};
         HIP_TRY(launch_lds_val(va, dpad / 32, stream));
         if (cs.cold_tiles > 0) {
             const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad};
@@ -846,7 +850,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (cs.flat_tpc) {
                 const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
-                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rlist, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rl2, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
                 HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
@@ -1032,7 +1036,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
     for (auto& cs : plan->lds) {
-        (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist);
+        (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist); (void)hipFree(cs.d_rl2);
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
         (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold); (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); (void)hipFree(cs.d_eidx16); (void)hipFree(cs.d_cold_eidx16);
     }

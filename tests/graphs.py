@@ -36,6 +36,19 @@ def powerlaw_graph(n, avg_deg, seed, alpha=1.8, symmetric=True):
     return csr_from_edges(src, dst, n)
 
 
+def community_graph(n, blocks, avg_deg, p_in, seed):
+    """Stochastic block model with consecutively numbered communities: a share p_in of the edges stays inside the endpoint's own
+    block (the shape tcgnn_graph.sbm_csr builds at Reddit size: a few column ranges per window are DENSE, the rest sparse)."""
+    rng = np.random.default_rng(seed)
+    m = int(n * avg_deg / 2)
+    src = rng.integers(0, n, size=m)
+    size = (n + blocks - 1) // blocks
+    inside = rng.random(m) < p_in
+    dst_in = np.minimum((src // size) * size + rng.integers(0, size, size=m), n - 1)
+    dst = np.where(inside, dst_in, rng.integers(0, n, size=m))
+    return csr_from_edges(np.concatenate([src, dst]), np.concatenate([dst, src]), n)
+
+
 def hub_rows_graph(n, seed, full_rows=24, half_rows=3, background=30000, bg_cols=None):
     """A few rows that are edges to every (or every second) column over a sparse uniform background, symmetrised: inside a hub's
     window a lane's run of edges within its eight tile columns is up to eight long (the edge-valued kernels fetch four values at a

@@ -647,6 +647,70 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
             assert np.abs(gemm["0"][0].cpu().numpy() - Z.cpu().numpy()).max() <= TIGHT * scale
 
 
+@pytest.mark.parametrize("D", [16, 32, 41, 48, 64, 128])
+@pytest.mark.parametrize("case", ["communities", "communities_some_cold", "denser_all_dense", "communities_default_threshold"])
+def test_flat_stream_with_dense_entries(dev, T, D, case, monkeypatch, capfd):
+    """r05: DENSE ENTRIES of the flat cell stream (tcgnn_lds_flat.inc).  A hot (workgroup, range) pair whose cells
+    overflow their one tile by much keeps all its columns in the LDS-resident walk: the tiles beyond each cell's first sit in dense
+    entries behind the workgroup's normal ones - ordinary-format tiles, a per-slot count word, a run-time loop per window slot.  On
+    community graphs (a window's own community = two dense column ranges of ~19 tiles per cell, N % 16 != 0), with every overflowing
+    pair dense, with only the community pairs dense and the rest of the overflow in the cold remainder, and with the default
+    threshold; every layout with a dense walk (1 - 2 planes x 4 / 8 windows; 48 columns = 3 planes has none and keeps the cold
+    remainder).  Against the oracle, fp64, the ordinary stream and the per-window gather walk; ReLU epilogue, the fused dense update
+    and determinism ride along."""
+    import tcgnn_capi as c
+    if case == "denser_all_dense":
+        rp, col = graphs.uniform_graph(3000, 400, seed=23)
+    else:
+        rp, col = graphs.community_graph(6061, 4, 300, 0.5, seed=5)      # N % 16 = 13
+    n = len(rp) - 1
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 17)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    W = (rng.standard_normal((D, 24)) / D ** 0.5).astype(np.float32)
+    tX, tW = to_dev(dev, X, W)
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    if case != "communities_default_threshold":
+        monkeypatch.setenv("TCGNN_LDS_DENSE_COLS", "5000" if case == "communities_some_cold" else "1")
+    out = {}
+    try:
+        for f in ("1", "0"):
+            monkeypatch.setenv("TCGNN_LDS_FLAT", f)
+            T.clear_plan_cache()
+            c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+            Y = T.forward(tX, *meta)[0]
+            out[f] = [Y, T.last_kernel(*meta), T.forward_fused(tX, *meta, relu=True)[0], T.forward(tX, *meta)[0]]
+            if D <= 64:
+                out[f] += [T.forward_gemm(tX, tW, *meta)[0], T.last_kernel(*meta)]
+        c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+        Y1 = T.forward(tX, *meta)[0]
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+    err = capfd.readouterr().err
+    Y, kernel, Yr, again = out["1"][:4]
+    assert kernel.startswith("spmm_lds_flat_kernel"), (kernel, err[-800:])
+    import re
+    dense = [int(x) for x in re.findall(r"entries \((\d+) dense\)", err)]
+    assert dense, err[-1500:]
+    if D == 48:
+        assert max(dense) == 0                       # the 3-plane pass has no dense walk
+    else:
+        assert max(dense) > 0, err[-1500:]
+    Y64, absY = O.spmm_f64(X, rp, col)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    assert_parity(Y.cpu().numpy(), ref, Y64, absY, "flat stream with dense entries")
+    assert_parity(out["0"][0].cpu().numpy(), ref, Y64, absY, "ordinary stream")
+    assert torch.equal(Y, again)
+    assert torch.equal(Yr, torch.relu(Y))
+    assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
+    if D <= 64:
+        Z, zkernel = out["1"][4:6]
+        want = (Y if zkernel.startswith("spmm_lds_flat_kernel") else Y1).double().cpu().numpy() @ W.astype(np.float64)
+        scale = np.abs(absY).max() * np.abs(W).sum(0).max() + 1.0
+        assert np.abs(Z.cpu().numpy() - want).max() <= 1e-5 * scale, (zkernel, np.abs(Z.cpu().numpy() - want).max())
+
+
 @pytest.mark.parametrize("shape", ["dense", "denser", "multi_edge_columns", "ragged"])
 @pytest.mark.parametrize("D", [64, 128])
 def test_edge_valued_spmm_on_the_lds_resident_walk(dev, T, D, shape, monkeypatch, capfd):
