@@ -784,7 +784,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             static bool attr_set = false;
             if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)val_permute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kValSpanHalves * 2)); attr_set = true; }
             hipLaunchKernelGGL(val_permute_kernel, dim3((unsigned)(cs.nwg * kLdsWaves * (kLdsMaxW2 / kValWpb))), dim3(kValThreads), kValSpanHalves * 2, stream, d_val, plan->rowptr, cs.d_order, cs.d_eidx16, cs.d_rbase, hdr,
-                               vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals);
+                               vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals, cs.d_rl2, cs.dense_entries > 0 ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
         const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rl2};

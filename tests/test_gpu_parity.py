@@ -597,6 +597,7 @@ def test_flat_cell_stream_matches_oracle_and_the_ordinary_stream(dev, T, D, flat
     W = (rng.standard_normal((D, 24)) / D ** 0.5).astype(np.float32)
     tX, tW = to_dev(dev, X, W)
     monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    monkeypatch.setenv("TCGNN_LDS_DENSE_COLS", "1000000000")   # (r05: no dense entries here - this test holds the COLD remainder of a flat stream; test_flat_stream_with_dense_entries has the other way)
     out, gemm = {}, {}
     try:
         for f in (flat, "0"):
@@ -766,13 +767,13 @@ def test_edge_valued_spmm_on_the_lds_resident_walk(dev, T, D, shape, monkeypatch
     assert np.abs(Y.cpu().numpy() - Y1.cpu().numpy()).max() <= TIGHT * (absY.max() + 1.0)
 
 
-def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=31):
+def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=31, graph=None, D=64):
     """forward_AGNN forced onto the LDS-resident edge-valued walk (mode 3 of ONE plan, stream built by prepare) -> (Y, kernel, refs)."""
-    rp, col = graphs.uniform_graph(3000, 200, seed=seed)
+    rp, col = graph if graph is not None else graphs.uniform_graph(3000, 200, seed=seed)
     n, nnz = len(rp) - 1, len(col)
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     rng = np.random.default_rng(seed)
-    X = (rng.standard_normal((n, 64)) * x_scale).astype(np.float32)
+    X = (rng.standard_normal((n, D)) * x_scale).astype(np.float32)
     att = att_fn(rng, nnz).astype(np.float32)
     tX, tatt = to_dev(dev, X, att)
     monkeypatch.setenv("TCGNN_LDS_FLAT", "1")
@@ -780,7 +781,7 @@ def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=3
     try:
         T.set_plan_modes(*meta, spmm_mode=3)
         if prepare:
-            T.prepare([64], *meta, edge_valued=True)
+            T.prepare([D], *meta, edge_valued=True)
         Y = T.forward_AGNN(tX, meta[0], meta[1], tatt.view(1, -1), *meta[2:])[0].cpu().numpy()
         kernel = T.last_kernel(*meta)
     finally:
@@ -788,6 +789,26 @@ def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=3
     ref = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
     Y64, absY = O.spmm_f64(X, rp, col, att)
     return Y, kernel, ref, Y64, absY
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("dense_cols", ["1", "5000", None])
+def test_edge_valued_lds_walk_with_dense_entries(dev, T, D, dense_cols, monkeypatch, capfd):
+    """r05: forward_AGNN on the flat single-edge stream WITH dense entries (a community's own column ranges hold ~20 tiles of edges
+    per cell): the values of a dense entry's tiles are brought into stream order by the window slot its descriptor names
+    (val_permute_kernel), the walk multiplies them from ordinary-format tiles.  Every overflowing pair dense / only the community
+    pairs (the rest in spmm_cold_val_kernel's remainder) / the default rule; N % 16 != 0."""
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    if dense_cols:
+        monkeypatch.setenv("TCGNN_LDS_DENSE_COLS", dense_cols)
+    g = graphs.community_graph(6061, 4, 300, 0.5, seed=5)
+    Y, kernel, ref, Y64, absY = _lds_val_case(dev, T, monkeypatch, lambda rng, nnz: rng.standard_normal(nnz), graph=g, D=D, seed=33)
+    err = capfd.readouterr().err
+    assert "spmm_lds_val_kernel" in kernel, (kernel, err[-1500:])
+    import re
+    dense = [int(x) for x in re.findall(r"entries \((\d+) dense\)", err)]
+    assert dense and max(dense) > 0, err[-1500:]
+    assert_parity(Y, ref, Y64, absY, "edge-valued walk with dense entries")
 
 
 def test_lds_val_walk_with_a_maximum_that_rounds_up_to_a_power_of_two(dev, T, monkeypatch):
