@@ -103,7 +103,7 @@ struct tcgnn_plan {
         int32_t* d_rbase = nullptr;        // [nwg + 1]
         int32_t* d_rlist = nullptr;        // [npairs + 4]
         // flat streams: the workgroup's walk as a list of ENTRIES (tcgnn_lds_flat.inc) - npairs and rbase then count entries, and
-        // d_rl2 [entries][16 wavefronts][2] holds the entry words (range | dense flag, next range / per-slot tile counts)
+        // d_rl2 holds [entries][4] entry records (range | flags, -, range to fetch, -) and behind them [entries][16 wavefronts] descriptor words
         uint32_t* d_rl2 = nullptr;
         int32_t dense_entries = 0;
         // cold remainder: columns of the (workgroup, range) pairs too thin for a range fill, re-condensed per window in the gather
@@ -784,10 +784,10 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             static bool attr_set = false;
             if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)val_permute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kValSpanHalves * 2)); attr_set = true; }
             hipLaunchKernelGGL(val_permute_kernel, dim3((unsigned)(cs.nwg * kLdsWaves * (kLdsMaxW2 / kValWpb))), dim3(kValThreads), kValSpanHalves * 2, stream, d_val, plan->rowptr, cs.d_order, cs.d_eidx16, cs.d_rbase, hdr,
-                               vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals, cs.d_rl2, cs.dense_entries > 0 ? 1 : 0);
+                               vals, plan->N, cs.cold_tiles > 0 ? cs.d_cold_ptr : nullptr, cs.d_cold_eidx16, cvals, cs.d_rl2, cs.dense_entries > 0 ? 1 : 0, std::max(cs.npairs, 1));
             HIP_TRY(hipGetLastError());
         }
-        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rl2};
+        const SpmmValArgs va{cs.d_flat, vals, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, 0, plan->Nc + 1, plan->nw_eff, cs.nwg, cs.d_rbase, cs.d_rl2, std::max(cs.npairs, 1)};
         HIP_TRY(launch_lds_val(va, dpad / 32, stream));
         if (cs.cold_tiles > 0) {
             const ColdValArgs ca{cs.d_cold_ptr, cs.d_cold_cols, cs.d_cold_mask, cvals, x16, hdr, d_Y, plan->N, D, plan->Nc + 1, plan->nw_eff, 0, dpad};
@@ -850,7 +850,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             if (cs.flat_tpc) {
                 const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
-                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rl2, d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
+                               has_cold ? 0 : relu, cs.d_rbase, cs.d_rl2, std::max(cs.npairs, 1), d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
                 HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
