@@ -188,14 +188,14 @@ int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode);
  *      max|X| - k max 2^-39 - and which ordinary training tensors never reach;
  *   2  (default since r04) also tcgnn_sddmm and the fused AGNN pair, whose bound is QUADRATIC - min(2 D, lost elements)
  *      max|X|^2 2^-39 - for what training produces: with the reference's unscaled weights an AGNN epoch's activations (max ~3e4,
- *      ONE element 2^28 below) cross that bound now and then.  Such a matrix has a handful of "dirty" rows: the MFMA kernels run
- *      as usual and one more launch recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch them
- *      (scores, their share of the aggregate and of d_w) - ~0.1 ms when it happens, a launch that returns at once when it does
- *      not.  Dirty rows are counted once per row (a row cut by a wavefront boundary of the conversion pass may count twice).  A matrix
- *      with MORE than 48 such rows (hub rows of a power-law graph under unscaled weights: the range is wide all
- *      over) stays on the MFMA path at this level and answers to the bound as documented;
- *   3  strict: such a matrix too is computed in plain fp32, CSR order (correct for any magnitudes, ~50x slower than the MFMA
- *      path on a Reddit-sized graph).
+ *      ONE element 2^28 below) cross that bound now and then.  Such a matrix has "dirty" rows - rows of X holding elements that lose
+ *      bits in the image; the conversion pass marks them in a bitmap behind the image - and the MFMA kernels run as usual while one
+ *      more launch scans the edges and recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch a
+ *      dirty row (scores, their share of the aggregate and of d_w): ~0.2 ms of scan plus a wavefront's work per such edge when it
+ *      happens, a launch that returns at once when it does not.  Any number of dirty rows (r04 patched at most 48 and left a matrix
+ *      with more - hub rows of a power-law graph under unscaled weights - to the bound above: closed in r05);
+ *   3  strict: a wide matrix is computed in plain fp32, CSR order, by SDDMM and the fused AGNN pair as well (correct for any
+ *      magnitudes, ~50x slower than the MFMA path on a Reddit-sized graph; level 2 gives the same guarantee at the cost of the dirty edges).
  * tcgnn_range_mode reports which way the LAST staged call on this workspace went: *wide_x = 1 if its feature matrix took the fp32
  * fallback as a binary SpMM / SDDMM / fused AGNN operand, 2 if it stayed on the MFMA path with its dirty rows patched (SDDMM /
  * fused AGNN), *wide_val (optional) = 1 if it took the fallback as an edge-valued SpMM.  Reads 40 bytes of the workspace header

@@ -1321,7 +1321,7 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
         T.clear_plan_cache()
 
 
-@pytest.mark.parametrize("specks", [1, 5, 12])
+@pytest.mark.parametrize("specks", [1, 5, 12, 300, -40])   # (300: far beyond r04's list of 48 rows; -40: 40 rows on a graph with hub rows, the hubs among them)
 def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks):
     """r04: the default guard level covers SDDMM and the fused AGNN pair.  What training produces is a matrix
     of 1e4-sized activations with ONE element 2^28 below the maximum (tools/probe_training_ranges.py): the quadratic bound makes it
@@ -1329,15 +1329,21 @@ def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks)
     Now the MFMA kernels run and wide_patch_kernel recomputes the edges that touch the few dirty rows in fp32: range_mode says 2,
     the scores of exactly those edges come out to accumulation accuracy of their own terms (the fp16 image alone misses by orders
     of magnitude there), everything else is untouched, aggregate and d_w follow."""
+    # r05 (VERDICT r04 item 2): ANY number of dirty rows - the conversion pass marks them in a bitmap, the patch scans the edges and
+    # recomputes every edge that touches one, a wavefront per edge; hub rows (thousands of edges each) are no special case.
     assert T.range_mode is not None
     T.set_range_guard(2)
-    rp, col = graphs.uniform_graph(4000, 100, seed=5)
+    hubs = specks < 0
+    specks = abs(specks)
+    rp, col = graphs.hub_rows_graph(2500, seed=77) if hubs else graphs.uniform_graph(4000, 100, seed=5)
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     n, D = len(rp) - 1, 64
     rng = np.random.default_rng(100 + specks)
     X = (rng.standard_normal((n, D)) * 1e4).astype(np.float32)
     X[np.abs(X) < 1.0] = 1.0
     rows = rng.choice(n, size=specks, replace=False)
+    if hubs:
+        rows[:8] = np.arange(8)                       # eight of the rows that are edges to every column
     for r in rows:
         X[r, rng.integers(0, D, size=3)] = 3e-5 * (1.0 + rng.random(3))       # ~2^30 below the maximum: fp16 subnormals lose most of their bits
     tX = torch.from_numpy(X).to(dev)
@@ -1348,7 +1354,7 @@ def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks)
     # sensitivity: the lost elements' own products are visible at this accuracy (each is ~3e-5 x 1e4 = 0.3 against sums of ~1e9 x 4e-6)
     erow = np.repeat(np.arange(n), np.diff(rp))
     touched = np.isin(erow, rows) | np.isin(col, rows)
-    assert touched.sum() >= specks * 100
+    assert touched.sum() >= specks * (20 if hubs else 100)
     w = np.float32(0.75)
     tw = torch.tensor([w], device=dev)
     Yf, ef_f, efm = T.agnn_fused_forward(tX, meta[0], meta[1], tw, *meta[2:])
@@ -1385,13 +1391,25 @@ def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks)
         T.clear_plan_cache()
 
 
-def test_agnn_training_with_the_reference_recipe_stays_inside_the_bar(dev, T):
+@pytest.mark.parametrize("graph", ["uniform", "powerlaw", "hub_rows", "rmat"])
+def test_agnn_training_with_the_reference_recipe_stays_inside_the_bar(dev, T, graph):
     """20 AGNN epochs with the reference's UNSCALED randn feature weights (gnn_conv.py:195 style activations of 1e4 and more) on a
     graph the oracle can follow: at the default guard level every fused forward call's scores and aggregate stay within
-    1e-3 max(1, |ref|) of an fp64 evaluation of the definition on the TF32-rounded operands, whichever way the guard sent the call."""
+    1e-3 max(1, |ref|) of an fp64 evaluation of the definition on the TF32-rounded operands, whichever way the guard sent the call.
+    r05: also on a power-law graph, on one with rows that are edges to every column, and on the R-MAT generator at
+    scale 0.05 - hub rows under unscaled weights are what r04's 48-row patch left to the documented bound."""
     import tcgnn_harness as H
     import tcgnn_layers as L
-    rp, col = graphs.uniform_graph(3000, 30, seed=8)
+    if graph == "uniform":
+        rp, col = graphs.uniform_graph(3000, 30, seed=8)
+    elif graph == "powerlaw":
+        rp, col = graphs.powerlaw_graph(3000, 30, seed=8)
+    elif graph == "hub_rows":
+        rp, col = graphs.hub_rows_graph(2500, seed=77)
+    else:
+        import tcgnn_graph as G
+        trp, tcol_ = G.rmat_csr(int(232965 * 0.05), int(114615892 * 0.05 * 0.05), seed=3)
+        rp, col = trp.numpy().astype(np.int32), tcol_.numpy().astype(np.int32)
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     n = len(rp) - 1
     erow = torch.from_numpy(np.repeat(np.arange(n), np.diff(rp))).to(dev)
@@ -1545,9 +1563,11 @@ def _wide_range_body(dev, T):
     assert T.range_mode()[0] == 1
     T.forward_ef(torch.from_numpy(X).to(dev), *meta)          # level 1: SDDMM answers to its documented bound
     assert T.range_mode()[0] == 0
-    T.set_range_guard(2)                                      # the default: a few dirty rows are patched (the test below), a matrix that is
-    T.forward_ef(torch.from_numpy(X).to(dev), *meta)          # wide all over - 3 999 dirty rows here - stays on the MFMA path as documented
-    assert T.range_mode()[0] == 0
+    T.set_range_guard(2)                                      # the default: dirty rows are patched - since r05 ANY number of them: a matrix that
+    ef = T.forward_ef(torch.from_numpy(X).to(dev), *meta)[0].cpu().numpy()   # is wide all over (3 999 dirty rows here) no longer answers to the documented bound
+    assert T.range_mode()[0] == 2
+    e64, ae64 = O.sddmm_f64(X, rp, col)
+    assert (np.abs(ef - e64) <= 2.0 ** -9 * (ae64 + 1e-30)).all()             # every score to the accuracy of its OWN terms (1e-6-sized products beside 3e4-sized ones)
     T.clear_plan_cache()
 
 
