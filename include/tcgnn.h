@@ -287,14 +287,16 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
  *
  * forward:   ef[e] = <X[row e], X[col e]>                         (= tcgnn_sddmm)
  *            Y     = A_att * X,  att[e] = fl32(w * ef[e])          (= tcgnn_spmm_val on w * ef)
- *            *d_ef_absmax = bit pattern of max |ef| (device word, consumed by the backward call)
+ *            d_ef_absmax: 1 + N device words the caller allocates - word 0 = bit pattern of max |ef|, words 1 .. N = the power-of-two
+ *            exponent each row's edge weights were scaled by (r05: one fp16 scale per ROW of A, so that small rows of a matrix whose
+ *            weights spread over 2^30 and more keep their mantissas) - consumed by the backward call
  * backward:  G     = A_att * dY, att[e] = fl32(w * ef[e]) with the saved ef   (gnn_conv.py:143)
  *            *d_dw = sum_e <dY[row e], dY[col e]> * (float)col(e)             (gnn_conv.py:150-153:
  *                    the reference's d_attention_w, mm(backward_ef(dY)[None,:], column_index[:,None].float()))
  * d_w is the attention weight as a DEVICE scalar (no host read-back).  Rounding is the same as in
- * the separate calls (10-bit mantissa operands, fp32 accumulate); the power-of-two scale of att comes
- * from a bound instead of a pass over E, so results equal the separate calls bit for bit unless an
- * edge weight is more than 2^-20 below that bound.  d_dw is a fixed-order reduction (deterministic).
+ * the separate calls (10-bit mantissa operands, fp32 accumulate); the power-of-two scale of row r's att comes
+ * from a bound (|w| D max|x_r| max|X|) instead of a pass over E, so results equal the separate calls bit for bit unless an
+ * edge weight is more than 2^-20 below its row's bound (a row whose neighbours' magnitudes spread that far).  d_dw is a fixed-order reduction (deterministic).
  * Supported for canonical plans (sorted, duplicate-free rows), D <= 128, E >= 8:
  * tcgnn_agnn_supported() tells; otherwise the calls return TCGNN_ERR_UNSUPPORTED and the caller
  * uses the three separate entry points. */

@@ -450,14 +450,14 @@ def _weight_scalar(attention_w, dev):
 def agnn_fused_forward(input, nodePointer, edgeList, attention_w, blockPartition, edgeToColumn, edgeToRow):
     """[Y, ef, ef_absmax] with ef = forward_ef(input), Y = forward_AGNN(input, attention_w * ef): what
     gnn_conv.py:125-132 computes with two calls (two gathers of the neighbour rows), here in one pass.
-    ef_absmax (one int32 word on the device) must be handed to agnn_fused_backward."""
+    ef_absmax (1 + N int32 words on the device: max |ef| and the per-row scale exponents) must be handed to agnn_fused_backward."""
     _six(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
     dev = input.device
     _weight_scalar(attention_w, dev)
     N, D = input.shape
     out = torch.empty_like(input)
     ef = torch.empty(edgeList.numel(), dtype=torch.float32, device=dev)
-    absmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    absmax = torch.zeros(1 + input.shape[0], dtype=torch.int32, device=dev)   # word 0: max |ef|; words 1 .. N: per-row exponents of the edge weights (include/tcgnn.h)
     with torch.cuda.device(dev):
         plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
         ws, ws_bytes = _workspace(plan, D, dev)
@@ -475,7 +475,7 @@ def agnn_fused_backward(d_output, nodePointer, edgeList, attention_w, ef, ef_abs
     _weight_scalar(attention_w, dev)
     _check_input(ef, "ef")
     _check_float(ef, "ef")
-    if ef.numel() != edgeList.numel() or ef_absmax.numel() != 1 or ef_absmax.dtype != torch.int32 or not ef_absmax.is_cuda:
+    if ef.numel() != edgeList.numel() or ef_absmax.numel() != 1 + d_output.shape[0] or ef_absmax.dtype != torch.int32 or not ef_absmax.is_cuda:
         raise RuntimeError("ef / ef_absmax are not what agnn_fused_forward returned for this graph")
     N, D = d_output.shape
     out = torch.empty_like(d_output)

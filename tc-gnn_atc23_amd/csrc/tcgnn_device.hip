@@ -801,7 +801,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
             AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, nullptr, const_cast<float*>(d_val), const_cast<uint32_t*>(hdr) + 1, ypart, partial,
                        plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, plan->nbuckets / ns, 0, plan->nw_eff, 0,
-                       image_is_big(plan->Nc, pitch), ns, 1};
+                       image_is_big(plan->Nc, pitch), ns, 1, nullptr};
             {
                 KernelTimer timer(plan, stream, "agnn_kernel (XCD-sliced, values only) + agnn_slice_sum_kernel");
                 HIP_TRY((launch_agnn<4, true, 0>(dpad / 16, a, ns * ((plan->nw_eff + 3) / 4), stream)));
@@ -945,7 +945,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
                plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
-               image_is_big(plan->Nc, pitch), 0, 0};
+               image_is_big(plan->Nc, pitch), 0, 0, reinterpret_cast<int32_t*>(d_absmax + 1)};   // (the per-row exponents of the edge weights sit behind the max |ef| word)
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));

@@ -1361,7 +1361,7 @@ def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks)
     assert T.range_mode()[0] == 2
     ef_fh = ef_f.cpu().numpy()
     assert (np.abs(ef_fh - refe) / (ae64 + 1e-30)).max() <= 4 * TIGHT
-    assert int(efm.item()) == int(np.abs(ef_fh).max().view(np.int32))
+    assert int(efm[0].item()) == int(np.abs(ef_fh).max().view(np.int32))
     att_ref = (w * ef_fh).astype(np.float32)
     refY = O.spmm_val(X, rp, col, att_ref, bp, e2c, e2r, round_mode=O.ROUND_TF32); _, aY = O.spmm_f64(X, rp, col, att_ref)
     assert (np.abs(Yf.cpu().numpy() - refY) / (aY + 1e-30)).max() <= 256 * TIGHT
@@ -1995,7 +1995,7 @@ def _wide_agnn_properties(dev, T, n, E, meta, D):
     assert T.agnn_fused_supported(X, *meta)
     Yf, ef_f, efm = T.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r)
     assert (ef_f - ef).abs().max().item() <= 1e-5 * (1.0 + ef.abs().max().item())
-    assert int(efm.item()) == int(ef_f.abs().max().reshape(1).view(torch.int32).item())
+    assert int(efm[0].item()) == int(ef_f.abs().max().reshape(1).view(torch.int32).item())
     att = (w * ef).view(1, -1).contiguous()
     Ys = T.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0]
     bound = (deg.sqrt()[:, None] * float(D) + 1.0)                           # |att| ~ 0.37 sqrt(D), |x| ~ 1: row sums ~ sqrt(deg D)
