@@ -368,7 +368,7 @@ def test_fused_agnn_products_equal_the_separate_calls_and_the_oracle(dev, T, cas
     Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
     ef_sep = T.forward_ef(tH, *meta)[0]
     assert torch.equal(ef, ef_sep), "fused scores differ from tcgnn_sddmm"
-    assert efmax.view(torch.float32).item() == ef_sep.abs().max().item()
+    assert efmax[:1].view(torch.float32).item() == ef_sep.abs().max().item()
     att = (tw.view(1, 1) * ef_sep.unsqueeze(0)).contiguous()
     Y_sep = T.forward_AGNN(tH, trp, tcol, att, tbp, te2c, te2r)[0]
     # same operand rounding, same accumulation order inside a wavefront's run of tiles; the two kernels cut a window's
@@ -908,7 +908,7 @@ def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatc
         G2, dw2 = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
         assert torch.equal(G, G2) and torch.equal(dw, dw2)
         assert ("XCD-sliced" in kf) == (sl != "0") and ("XCD-sliced" in T.last_kernel(*meta)) == (sl != "0"), (sl, kf)
-        out[sl] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax.item(), G.cpu().numpy(), float(dw))
+        out[sl] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax[0].item(), G.cpu().numpy(), float(dw))
     att = (np.float32(-1.3) * out["0"][1]).astype(np.float32)
     Y64, absY = O.spmm_f64(H, rp, col, att)
     G64, absG = O.spmm_f64(dY, rp, col, att)
@@ -1012,7 +1012,7 @@ def test_fused_agnn_range_major_walk_equals_per_window_walk(dev, T, D):
             c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
             Y, ef, efmax = T.agnn_fused_forward(tH, trp, tcol, tw, tbp, te2c, te2r)
             G, dw = T.agnn_fused_backward(tdY, trp, tcol, tw, ef, efmax, tbp, te2c, te2r)
-            out[mode] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax.item(), G.cpu().numpy(), float(dw))
+            out[mode] = (Y.cpu().numpy(), ef.cpu().numpy(), efmax[0].item(), G.cpu().numpy(), float(dw))
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
     ef_ref = O.sddmm(H, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
