@@ -697,6 +697,14 @@ def multi_gpu(args):
     except Exception as exc:   # an extra: must never take the headline down
         if rank == 0:
             print("fp16-exchange leg failed: %s" % str(exc)[:300], file=sys.stderr)
+    # ---- the exchange in 32-column chunks through a ring of two buffers (RowShard.spmm_chunked: what config 5 needs to fit)
+    t_chunk = float("nan")
+    try:
+        wc = lambda: shard.spmm_chunked(x_local, chunk=32, wire="fp32")
+        t_chunk = sync_time(wc, max(3, args.steps // 5), 2, barrier) * args.steps / max(3, args.steps // 5)
+    except Exception as exc:   # an extra: must never take the headline down
+        if rank == 0:
+            print("chunked-exchange leg failed: %s" % str(exc)[:300], file=sys.stderr)
     # ---- the exchange overlapped with the own-block product (RowShard.spmm_overlapped: the gather on a side stream)
     t_overlap = float("nan")
     try:
@@ -720,7 +728,7 @@ def multi_gpu(args):
     except Exception as exc:   # the extra leg must never take the headline down
         if rank == 0:
             print("sharded GCN leg failed: %s" % str(exc)[:300], file=sys.stderr)
-    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16, t_overlap], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16, t_overlap, t_chunk], dtype=torch.float64, device=dev)
     mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     out = None
@@ -749,6 +757,7 @@ def multi_gpu(args):
                       # the gather on a side stream under the product over the rank's own column block (RowShard.spmm_overlapped)
                       "ms_per_step_with_overlapped_exchange": None if np.isnan(float(mx[7])) else round(float(mx[7]) * 1e3 / args.steps, 4),
                       "exchange_fraction_if_overlapped": None if np.isnan(float(mx[7])) else round(max(0.0, 1.0 - t_local / float(mx[7])), 4),
+                      "ms_per_step_with_chunked_exchange_32col_fp32": None if np.isnan(float(mx[8])) else round(float(mx[8]) * 1e3 / args.steps, 4),
                       "own_block_edge_fraction": round(float(getattr(shard, "_own_frac", float("nan"))), 4)},
         }
     dist.barrier()
@@ -808,22 +817,29 @@ def plan_only(args):
         csr = 4 * (rows_r + 1) + 4 * nnz_r
         sgt = 4 * nw + 8 * nnz_r
         plan = int(wide * 256 + 8 * (nw + 1) + 4 * nw)
-        image = 256 + (ncols + 1) * x16_pitch_halves(dpad) * 2
-        gather = 4 * D * (ncols + H)                                      # recv + send of RowShard.gather (fp32)
         widest = max(D, classes)
-        gather_all = 4 * (ncols + H) * (D + classes)                      # one buffer pair per width used (D and the class layer)
         feats = 4 * rows_r * in_dim
         acts = 4 * rows_r * (2 * D + 2 * classes) * 2                     # X W, A(X W) per layer, and their gradients
+        # ---- the exchange.  r05 default (tcgnn_shard.RowShard.spmm_chunked, exchange_chunk = 64): the matrix crosses the fabric 64
+        #      columns at a time as the kernels' fp16 image - every rank converts only its rows - into a ring of TWO image buffers
+        #      that tcgnn_spmm_staged multiplies from; no fp32 copy of the gathered matrix exists.  Whole-matrix fp32 gather (r01-r04):
+        #      one receive + send buffer pair per width in use and the image of the widest layer - reported next to it.
+        chunk = min(64, widest)
+        cpitch = x16_pitch_halves((chunk + 15) // 16 * 16)
+        image_ring = 2 * (256 + (ncols + 1) * cpitch * 2)
+        send_ring = 2 * (H + 1) * cpitch * 2
+        chunk_temps = 4 * rows_r * chunk + 2 * 4 * rows_r * widest          # the chunk's columns of X made contiguous; the chunks of Y and their concatenation
+        parts = {"csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan, "exchange_image_ring_bytes": image_ring,
+                 "exchange_send_ring_bytes": send_ring, "exchange_chunk_temporaries_bytes": chunk_temps, "features_bytes": feats, "layer_tensors_bytes": acts}
+        total = sum(parts.values())
         image_w = 256 + (ncols + 1) * x16_pitch_halves((widest + 15) // 16 * 16) * 2
-        total = csr + sgt + plan + image_w + gather_all + feats + acts
-        # (the listed parts are the ones summed - the image of the WIDEST layer and the gather buffers of BOTH widths;
-        #  the hidden-width figures ride along under *_hidden_only and are not part of the sum)
-        parts = {"csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan, "image_fp16_widest_layer_bytes": image_w,
-                 "gather_buffers_all_widths_bytes": gather_all, "features_bytes": feats, "layer_tensors_bytes": acts}
-        assert sum(parts.values()) == total
+        gather_all = 4 * (ncols + H) * (D + classes)                      # one fp32 buffer pair per width used (D and the class layer)
+        total_whole = csr + sgt + plan + image_w + gather_all + feats + acts
         out_rows.append({"rank": r, "rows": rows_r, "edges": nnz_r, "gathered_rows": ncols, **parts,
-                         "image_fp16_hidden_only_bytes": image, "gather_buffer_hidden_only_bytes": gather,
-                         "total_bytes": total, "parts_summed": sorted(parts), "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES})
+                         "total_bytes": total, "parts_summed": sorted(parts), "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES,
+                         "exchange": "64-column chunks, fp16 image on the wire, ring of two buffers (RowShard.spmm_chunked)",
+                         "whole_matrix_fp32_exchange": {"image_fp16_widest_layer_bytes": image_w, "gather_buffers_all_widths_bytes": gather_all,
+                                                        "total_bytes": total_whole, "frac_of_hbm": round(total_whole / HBM_BYTES, 4)}})
     H = per[0][2]
     blk32, blk16 = 4 * H * D, 2 * H * x16_pitch_halves((D + 15) // 16 * 16)
     doc = {"plan_only": True, "workload": "%s GCN hidden=%d, rows sharded over %d GPUs (BASELINE.json configs[4])" % (shape, D, world),

@@ -135,15 +135,30 @@ class HipShardOps:
             self.c.check(self.c.lib.tcgnn_spmm(self.plan, Xg.data_ptr(), Y.data_ptr(), D, ws, nb, torch.cuda.current_stream(self.dev).cuda_stream), "tcgnn_spmm")
         return Y
 
-    def spmm_fp16_exchange(self, x_local, layout, rank, group=None, always_collective=False):
+    def spmm_fp16_exchange(self, x_local, layout, rank, group=None, always_collective=False, slot=0):
         """Y_local = A_local @ X with fp16 on the wire: this rank converts ITS rows to the kernels' scaled fp16 image (global
         max|X| from a one-word all-reduce), the image slices are all-gathered (half the bytes of the fp32 gather, and no rank
         stages the whole gathered matrix again) and the SpMM reads the image directly (tcgnn_spmm_staged)."""
+        image = self.exchange_fp16(x_local, layout, rank, group, always_collective, slot)
+        return self.spmm_from_image(image, x_local.shape[1])
+
+    def spmm_from_image(self, image, D):
+        """Y_local = A_local @ X from a gathered fp16 image (exchange_fp16)."""
+        c, dev = self.c, self.dev
+        with torch.cuda.device(dev):
+            Y = torch.empty(self.rows, D, device=dev)
+            c.check(c.lib.tcgnn_spmm_staged(self.plan, image.data_ptr(), Y.data_ptr(), D, torch.cuda.current_stream(dev).cuda_stream), "tcgnn_spmm_staged")
+        return Y
+
+    def exchange_fp16(self, x_local, layout, rank, group=None, always_collective=False, slot=0):
+        """The exchange half of spmm_fp16_exchange: abs-max word (all-reduce MAX), this rank's rows -> scaled fp16, all-gather of
+        the image slices into image buffer `slot` (a ring of two lets the exchange of one column chunk run under the multiply
+        of the chunk before: RowShard.spmm_chunked).  -> the image (header + rows), ready for spmm_from_image."""
         c, dev = self.c, self.dev
         rows, D = x_local.shape
         H, world = layout.H, layout.world
         pitch = c.lib.tcgnn_x16_pitch(D)
-        key = ("wire16", D)
+        key = ("wire16", D, slot)
         buf = getattr(self, "_wire", {}).get(key)
         if buf is None:
             image = torch.zeros(256 + (self.num_cols + 1) * pitch * 2 + 256, dtype=torch.uint8, device=dev)
@@ -170,9 +185,7 @@ class HipShardOps:
                 all_gather_rows(body[: world * H].view(-1), send[:H].view(-1), group)
             else:
                 body[:H].copy_(send[:H])
-            Y = torch.empty(self.rows, D, device=dev)
-            c.check(c.lib.tcgnn_spmm_staged(self.plan, image.data_ptr(), Y.data_ptr(), D, st), "tcgnn_spmm_staged")
-        return Y
+        return image
 
     def spmm_val(self, Xg, val):
         self._check(Xg)
@@ -213,12 +226,12 @@ class _GatherSpmm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_local, shard):
         ctx.shard = shard
-        return shard.ops.spmm(shard.gather(x_local))
+        return shard.exchange_spmm(x_local)
 
     @staticmethod
     def backward(ctx, d_out):
         shard = ctx.shard  # A, not A^T: the reference's symmetric-graph convention (gnn_conv.py:46)
-        return shard.ops.spmm(shard.gather(d_out.contiguous())), None
+        return shard.exchange_spmm(d_out.contiguous()), None
 
 
 class RowShard:
@@ -244,11 +257,14 @@ class RowShard:
         return shard
 
     def __init__(self, row_pointers=None, column_index=None, rank=None, world_size=None, device=None, group=None,
-                 ops_factory=None, bounds=None, local=None, always_collective=None, local_is_remapped=False):
+                 ops_factory=None, bounds=None, local=None, always_collective=None, local_is_remapped=False, exchange_chunk=None):
         """Either the whole CSR (row_pointers, column_index; every rank holds it or builds it the
         same way) or `local=(local_row_pointers, global_column_ids)` + `bounds` when each rank only
         ever materialises its own rows (graphs too large for one host/GPU)."""
         self.group = group
+        # columns per exchange of `aggregate` / `exchange_spmm` (None: the whole matrix in one gather - the r01-r04 form; 64: the
+        # chunked exchange of spmm_chunked, what a graph of papers100M's size needs to fit - bench.py --plan-only)
+        self.exchange_chunk = exchange_chunk if exchange_chunk is not None else (int(os.environ["TCGNN_SHARD_EXCHANGE_CHUNK"]) if os.environ.get("TCGNN_SHARD_EXCHANGE_CHUNK") else None)
         # a world of one normally skips the exchange; with this switch it still issues every collective of the N-rank step
         # (all_gather_into_tensor of X / of the fp16 image slices, the one-word all_reduce(MAX)): how a 1-GPU box rehearses
         # the RCCL calls of the 8-GPU run (bench.py with TCGNN_BENCH_FORCE_SHARDED=1, tests/test_gpu_sharded.py)
@@ -352,6 +368,77 @@ class RowShard:
         send.record_stream(side)
         recv.record_stream(side)
         return y.add_(rest.spmm(recv))
+
+    # ---- the exchange in COLUMN CHUNKS (r05).  One gather of the whole N x D matrix needs
+    # world * H * D fp32 words of receive buffer per width in use - 118 GB of a papers100M rank's 288 (bench.py --plan-only) - plus
+    # the kernels' fp16 image of the same matrix.  Here the matrix crosses the fabric `chunk` columns at a time into a RING OF
+    # TWO buffers: while the kernel multiplies chunk k out of one buffer the exchange of chunk k + 1 fills the other (side
+    # stream).  With fp16 on the wire (the default from 64 columns up, where a row of the image is a whole 128-byte line) every
+    # rank converts only ITS rows, the gathered buffer IS the kernels' image (tcgnn_spmm_staged) and no fp32 copy of the gathered
+    # matrix exists at all: 2 x 14.2 GB instead of 118 + 42.6 GB per papers100M rank.  Results: a column of Y depends on that
+    # column of X alone, and rounding to a 10-bit mantissa does not depend on the per-chunk power-of-two scale - so every chunk
+    # equals the same columns of the whole-matrix call on the same walk, bit for bit.
+    def spmm_chunked(self, x_local, chunk=64, wire="auto"):
+        D = x_local.shape[1]
+        chunk = max(16, int(chunk))
+        if wire == "auto":
+            wire = "fp16" if (min(chunk, D) >= 64 and hasattr(self.ops, "exchange_fp16")) else "fp32"
+        if wire == "fp16" and not hasattr(self.ops, "exchange_fp16"):
+            wire = "fp32"
+        collective = self.world > 1 or self.always_collective
+        starts = list(range(0, D, chunk))
+        gpu = x_local.is_cuda
+        outs = [None] * len(starts)
+
+        def exchange(k):   # chunk k -> ring slot k & 1
+            xc = x_local[:, starts[k]: starts[k] + chunk].contiguous()
+            if wire == "fp16":
+                return self.ops.exchange_fp16(xc, self.layout, self.rank, self.group, self.always_collective, slot=k & 1)
+            H, dc = self.layout.H, xc.shape[1]
+            key = ("chunk", dc, xc.dtype, k & 1)
+            buf = self._gbuf.get(key)
+            if buf is None:
+                buf = (torch.zeros(H, dc, dtype=xc.dtype, device=xc.device), torch.empty(self.world * H, dc, dtype=xc.dtype, device=xc.device))
+                self._gbuf[key] = buf
+            send, recv = buf
+            send[: self.rows].copy_(xc)
+            if not collective:
+                return send
+            all_gather_rows(recv, send, self.group)
+            return recv
+
+        def multiply(k, g):
+            dc = min(chunk, D - starts[k])
+            return self.ops.spmm_from_image(g, dc) if wire == "fp16" else self.ops.spmm(g)
+
+        if not gpu:           # (CPU stand-in of the tests: no streams)
+            for k in range(len(starts)):
+                outs[k] = multiply(k, exchange(k))
+            return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+        main = torch.cuda.current_stream(x_local.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=x_local.device)
+        side = self._side
+        side.wait_stream(main)                       # x_local is ready; the ring's previous readers are done
+        done = [None, None]                          # per ring slot: the multiply that read it last
+        for k in range(len(starts)):
+            with torch.cuda.stream(side):
+                if done[k & 1] is not None:
+                    side.wait_event(done[k & 1])     # the multiply of chunk k - 2 has finished with this slot
+                g = exchange(k)
+                ready = torch.cuda.Event(); ready.record(side)
+            main.wait_event(ready)
+            outs[k] = multiply(k, g)
+            done[k & 1] = torch.cuda.Event(); done[k & 1].record(main)
+            g.record_stream(main)
+        main.wait_stream(side)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+
+    def exchange_spmm(self, x_local):
+        """What `aggregate` runs in either direction: the whole-matrix gather, or - exchange_chunk set - the chunked exchange."""
+        if self.exchange_chunk:
+            return self.spmm_chunked(x_local, self.exchange_chunk)
+        return self.ops.spmm(self.gather(x_local))
 
     def place_replicated(self, x_global):
         """No exchange: scatter a replicated [N, D] matrix into the gathered numbering (graphs

@@ -100,7 +100,8 @@ def test_plan_only_prints_the_per_rank_memory_plan_of_config_5(tmp_path):
         assert x["edges"] < 2 ** 31 and x["rows"] % 16 == 0 or x["rank"] == 7
         assert x["total_bytes"] == sum(x[k] for k in x["parts_summed"]) and x["total_bytes"] < doc["hbm_bytes_per_gpu"]   # (the listed parts add up)
         assert {"csr_bytes", "sgt_metadata_bytes", "plan_bytes_est", "features_bytes", "layer_tensors_bytes"} <= set(x["parts_summed"])
-        assert x["image_fp16_hidden_only_bytes"] == 256 + (x["gathered_rows"] + 1) * 128          # D = 64: one 128-byte line per row
+        assert x["exchange_image_ring_bytes"] == 2 * (256 + (x["gathered_rows"] + 1) * 128)     # two 64-column fp16 images: one 128-byte line per row each
+        assert x["frac_of_hbm"] <= 0.55 and x["whole_matrix_fp32_exchange"]["frac_of_hbm"] > x["frac_of_hbm"]   # (headroom for config 5)
     ex = doc["exchange_per_spmm"]
     assert ex["fp16_block_bytes"] * 2 == ex["fp32_block_bytes"] and 20 < ex["fp32_ms_link_bound"] < 26    # ~23 ms fp32, ~12 ms fp16
     # with shard files: rows and edges per rank are the files'

@@ -69,6 +69,9 @@ def _worker(rank, world, port, out_dir):
                         a = shard.spmm(x_local)
                         b = shard.spmm(x_local, wire="fp16")
                         ok[tag + "fp16 wire == fp32 wire (mode %d)" % mode] = bool(torch.equal(a, b))
+                        # r05: the exchange in column chunks (ring of two buffers, side stream) equals the whole-matrix one on the same walk
+                        for ch, wr in ((16, "fp32"), (32, "fp32"), (64, "auto"), (32, "fp16")):
+                            ok[tag + "chunked exchange %d cols / %s (mode %d)" % (ch, wr, mode)] = bool(torch.equal(a, shard.spmm_chunked(x_local, chunk=ch, wire=wr)))
                 finally:
                     c.lib.tcgnn_set_spmm_mode(0)
                 Yo = shard.spmm_overlapped(x_local)                      # gather on a side stream under the own-block product
@@ -294,6 +297,12 @@ def _rccl_worker(rank, world, port, out_dir):
             ok["D=%d sddmm" % D] = bool(torch.equal(plain.sddmm(X), coll.sddmm(X)))
             a = plain.spmm(X)
             ok["D=%d overlapped exchange (side-stream all-gather under RCCL)" % D] = bool(((coll.spmm_overlapped(X) - a).abs().max() <= 1e-4 * (a.abs().max() + 1.0)).item())
+            try:   # the chunked exchange's collectives on the side stream under RCCL (fp16 image slices from 64 columns up, fp32 below)
+                c.check(c.lib.tcgnn_set_spmm_mode(1), "tcgnn_set_spmm_mode")
+                a1 = plain.spmm(X)
+                ok["D=%d chunked exchange under RCCL" % D] = bool(torch.equal(a1, coll.spmm_chunked(X, chunk=64)) and torch.equal(a1, coll.spmm_chunked(X, chunk=16, wire="fp32")))
+            finally:
+                c.lib.tcgnn_set_spmm_mode(0)
         # one whole training step with the gradient / loss all-reduces issued
         in_dim, hidden, classes = 20, 16, 5
         Xf = torch.randn(n, in_dim, device=dev) * 0.1

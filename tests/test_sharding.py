@@ -91,6 +91,18 @@ def _worker(rank, world, port, out_dir):
         ok["sddmm"] = np.allclose(shard.sddmm(x_local).numpy(), ef[e0:e1], atol=1e-4)
         # the exchange overlapped with the own-block product: A_local = [A_own | A_rest], same result up to summation order
         ok["overlapped"] = np.allclose(shard.spmm_overlapped(x_local).numpy(), Yfull[b0:b1], atol=1e-5) and 0.0 < shard._own_frac < 1.0
+        # r05: the exchange in column chunks through a ring of two buffers equals the whole-matrix exchange -
+        # a column of Y depends on that column of X alone - for a chunk that divides D, one that does not, and one wider than D;
+        # and `aggregate` takes that road, forward and backward, when the shard is built with exchange_chunk
+        whole = shard.spmm(x_local)
+        ok["chunked"] = all(torch.equal(shard.spmm_chunked(x_local, chunk=ch, wire="fp32"), whole) for ch in (16, 8 + 8, 32, 64))
+        shard_c = S.RowShard(rp, col, ops_factory=OracleShardOps, exchange_chunk=16)
+        xl2 = x_local.clone().requires_grad_(True)
+        yc = shard_c.aggregate(xl2)
+        yc.sum().backward()
+        xl3 = x_local.clone().requires_grad_(True)
+        shard.aggregate(xl3).sum().backward()
+        ok["chunked_autograd"] = torch.equal(yc.detach(), whole) and torch.equal(xl2.grad, xl3.grad)
         # replicated placement (no exchange) gives the same gathered matrix as the collective
         ok["replicated"] = torch.equal(shard.place_replicated(torch.from_numpy(X)), shard.gather(x_local))
         # local-only construction (each rank materialises just its rows)
