@@ -1697,6 +1697,34 @@ def test_full_size_reddit_shape_properties(dev, T):
     T.clear_plan_cache()
 
 
+def test_full_size_sbm_reddit_headline_graph_against_the_oracle(dev, T, capfd, monkeypatch):
+    """r05: the HEADLINE graph - Reddit shape from the SBM calibrated to real Reddit's TC-block count - at full
+    size: A @ 1 = degree exactly, and the oracle's own window bodies on 256 sampled windows for forward, forward_AGNN, forward_ef
+    and the fused pair, for the automatic kernels (the flat stream WITH dense entries: spmm_lds_flat_kernel; the edge-valued walk
+    with dense entries: spmm_lds_val_kernel), both forced gather walks and the ordinary LDS stream."""
+    import tcgnn_graph as G
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    n, nnz, _, _ = G.SHAPES["reddit"]
+    rp, col = G.GENERATORS["sbm_reddit"](n, nnz, seed=0, device=dev)
+    E = col.numel()
+    nw = (n + 15) // 16
+    bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+    T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+    meta = (rp, col, bp, e2c, e2r)
+    assert abs(T.plan_info(*meta)["tc_blocks"] - 13566510) / 13566510 < 0.01          # /root/reference/logs/reduce_blocks.csv:18 (real Reddit)
+    deg = (rp[1:] - rp[:-1]).float()
+    assert torch.equal(T.forward(torch.ones(n, 64, device=dev), *meta)[0], deg[:, None].expand(-1, 64))
+    kernels = _sampled_oracle_checks(dev, T, n, E, meta, 64, lds_ordinary=True)
+    err = capfd.readouterr().err
+    if os.environ.get("TCGNN_LDS_AUTO", "1") != "0":
+        assert kernels["automatic spmm"].startswith("spmm_lds_flat_kernel"), kernels
+        assert "spmm_lds_val_kernel" in kernels["automatic spmm_val"], kernels
+        import re
+        dense = [int(x) for x in re.findall(r"entries \((\d+) dense\)", err)]
+        assert len(dense) >= 2 and min(dense[:2]) > 1000, err[-2000:]                 # both streams carry dense entries
+    T.clear_plan_cache()
+
+
 def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary=False):
     """VERDICT r03 "oracle evidence at BASELINE size": the full-size tests above assert size-independent properties; here the SAME
     launches are compared with the ORACLE itself on a sample - `nwin` random row windows (16 rows each: 4 096 rows, ~1-2 M edges

@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tc-gnn_atc23_amd"))
-TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r05"
 QUICK = "--quick" in sys.argv
 ALLGEN = "--all-generators" in sys.argv
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + TAG)
@@ -107,13 +107,16 @@ def main():
         pass
     if not QUICK:
         harness = [sys.executable, os.path.join(ROOT, "tc-gnn_atc23_amd", "tcgnn_harness.py"), "--synthetic", "reddit", "--dim", "602", "--hidden", "64",
-                   "--classes", "41", "--epochs", "10", "--gpu_preprocess", "--model"]
-        stats(harness + ["gcn"], "epoch_gcn")
-        stats(harness + ["agnn"], "epoch_agnn")
+                   "--classes", "41", "--epochs", "10", "--gpu_preprocess"]
+        # (r05: the headline graph is sbm_reddit - bench.py --graph; the uniform graph of r01-r04 next to it)
+        for gen, suffix in (("sbm_reddit", ""), ("uniform", "_uniform")):
+            stats(harness + ["--generator", gen, "--model", "gcn"], "epoch_gcn" + suffix)
+            stats(harness + ["--generator", gen, "--model", "agnn"], "epoch_agnn" + suffix)
+        stats([sys.executable, os.path.join(ROOT, "tools", "bench_val.py"), "reddit", "sbm_reddit", "64"], "forward_agnn_sbm_reddit_d64")
     rows = []
-    work = [("reddit", "uniform", 64)] if QUICK else [("reddit", "uniform", 64), ("ogbn-products", "uniform", 128)]
+    work = [("reddit", "sbm_reddit", 64)] if QUICK else [("reddit", "sbm_reddit", 64), ("reddit", "uniform", 64), ("ogbn-products", "uniform", 128)]
     if ALLGEN:
-        work += [("reddit", "sbm_reddit", 64), ("reddit", "sbm", 64), ("reddit", "rmat", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]   # (bench.py's default dataset list)
+        work += [("reddit", "sbm", 64), ("reddit", "rmat", 64), ("ogbn-products", "sbm", 128), ("ogbn-products", "rmat", 128)]   # (bench.py's default dataset list)
     for shape, gen, D in work:
         rows += pmc_workload(shape, gen, D)
     json.dump({"build_id": bid, "round": TAG, "how": __doc__.split("3. traffic.json:")[1].strip(), "rows": rows},
