@@ -941,7 +941,7 @@ def compact_line(out, limit=LINE_LIMIT):
     if isinstance(beat, dict):
         summary.append(("artifact_shapes_beating_rtx3090", "%s/%s spmm_d16, %s/%s gcn_h16" % (beat.get("spmm_d16"), beat.get("of"), beat.get("gcn_h16_epoch"), beat.get("of"))))
     for k in ("exchange_in_timed_step", "ms_per_step_without_exchange", "exchange_fraction_if_exchanged", "gcn_ms_per_epoch_sharded",
-              "ms_per_step_with_fp16_exchange", "ms_per_step_with_overlapped_exchange"):   # (the N > 1 line)
+              "ms_per_step_with_fp16_exchange", "ms_per_step_with_overlapped_exchange", "ms_per_step_with_chunked_exchange_32col_fp32"):   # (the N > 1 line)
         if k in ex:
             summary.append((k, ex[k]))
     summary = [(k, v) for k, v in summary if v is not None]
