@@ -24,8 +24,14 @@ def wrap(name, fn, idx=0):
         nz = x[x > 0]
         mx = float(x.max()); mn = float(nz.min()) if nz.numel() else 0.0
         tiny = int((nz < mx * 2.0 ** -28).sum())
+        # r05: the rows that hold such elements (the patch's dirty rows) and the edges that touch them (what the patch recomputes)
+        xa = a[idx].detach().abs()
+        drow = ((xa > 0) & (xa < mx * 2.0 ** -28)).any(1)
+        ndirty = int(drow.sum())
+        deg = (rp[1:] - rp[:-1]).long()
+        dedges = int(2 * deg[drow].sum())
         out = fn(*a, **k)
-        seen.append((name, tuple(a[idx].shape), mx, mn, tiny, TCGNN.range_mode()))
+        seen.append((name, tuple(a[idx].shape), mx, mn, tiny, TCGNN.range_mode(), ndirty, dedges))
         return out
     return f
 for name in ("forward", "forward_fused", "forward_gemm", "forward_AGNN", "forward_ef", "agnn_fused_forward", "agnn_fused_backward"):
@@ -36,4 +42,4 @@ for model in ("gcn", "agnn"):
     H.time_training(model, meta, feats, labels, in_dim, 64, classes, 2, 1, seed=0, warmup=2, tune=False)
     print(model, gen)
     for s in seen[-8:]:
-        print("   %-20s %-16s max %.3e  min nonzero %.3e  (2^%.1f below)  tiny %d  guard %s" % (s[0], s[1], s[2], s[3], (torch.log2(torch.tensor(s[2] / max(s[3], 1e-45)))).item(), s[4], s[5]))
+        print("   %-20s %-16s max %.3e  min nonzero %.3e  (2^%.1f below)  tiny %d  guard %s  dirty rows %d (~%d edges)" % (s[0], s[1], s[2], s[3], (torch.log2(torch.tensor(s[2] / max(s[3], 1e-45)))).item(), s[4], s[5], s[6], s[7]))

@@ -27,6 +27,11 @@ for k in range(cases):
     os.environ.pop("TCGNN_LDS_PLACE", None); os.environ.pop("TCGNN_LDS_HOT_COLS", None)
     if place != "auto": os.environ["TCGNN_LDS_PLACE"] = place
     if hot: os.environ["TCGNN_LDS_HOT_COLS"] = str(hot)
+    # r05: flat streams with dense entries - the automatic rule, every overflowing pair dense, some, none; the flat stream forced or not
+    dense = str(rng.choice(["auto", "auto", "1", "200", "5000", "1000000000"])); flat = str(rng.choice(["auto", "auto", "1"]))
+    os.environ.pop("TCGNN_LDS_DENSE_COLS", None); os.environ.pop("TCGNN_LDS_FLAT", None)
+    if dense != "auto": os.environ["TCGNN_LDS_DENSE_COLS"] = dense
+    if flat != "auto": os.environ["TCGNN_LDS_FLAT"] = flat
     n = rp.numel() - 1; E = col.numel(); nw = (n + 15) // 16
     bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
     os.dup2(fd, 1); TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r); os.dup2(sv, 1)
@@ -45,8 +50,8 @@ for k in range(cases):
     err = ((out[1] - out[3]).abs() / scale).max().item()
     worst = max(worst, err)
     maxdeg = int((rp[1:] - rp[:-1]).max())
-    print("case %2d: %-8s N=%6d E=%9d D=%3d skew %.1f maxdeg %6d place %-10s hot %4d %-48s: |lds - plain| / scale = %.2e" % (
-        k, gen, n, E, D, skew, maxdeg, place, hot, lds_kernel, err), flush=True)
+    print("case %2d: %-8s N=%6d E=%9d D=%3d skew %.1f maxdeg %6d place %-10s hot %4d dense %-10s flat %-4s %-48s: |lds - plain| / scale = %.2e" % (
+        k, gen, n, E, D, skew, maxdeg, place, hot, dense, flat, lds_kernel, err), flush=True)
     assert err < 2e-3, "mismatch"
     TCGNN.clear_plan_cache() if hasattr(TCGNN, "clear_plan_cache") else None
     del rp, col, bp, e2c, e2r, X, out; torch.cuda.empty_cache()

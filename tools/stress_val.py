@@ -26,6 +26,9 @@ for k in range(cases):
     bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
     os.dup2(fd, 1); TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r); os.dup2(sv, 1)
     meta = (rp, col, bp, e2c, e2r)
+    dense = str(rng.choice(["auto", "auto", "1", "200", "5000", "1000000000"]))   # r05: dense entries of the single-edge stream
+    os.environ.pop("TCGNN_LDS_DENSE_COLS", None)
+    if dense != "auto": os.environ["TCGNN_LDS_DENSE_COLS"] = dense
     X = torch.randn(n, D, device=dev) * float(rng.choice([1e-3, 1.0, 50.0]))
     att = torch.randn(1, E, device=dev) * float(rng.choice([0.01, 1.0, 30.0]))
     c.check(c.lib.tcgnn_set_spmm_mode(3), "mode")
@@ -44,7 +47,7 @@ for k in range(cases):
     e3 = ((Y3.double() - Y64).abs() / (tol + 1e-300)).max().item(); e1 = ((Y1.double() - Y64).abs() / (tol + 1e-300)).max().item()
     d13 = ((Y3 - Y1).abs().double() / (absY + 1e-30)).max().item()
     worst = max(worst, e3); taken += "lds_val" in kernel
-    print("case %2d: %-8s N=%6d E=%9d D=%3d  %-60s err/bound lds %.3f gather %.3f  |lds - gather| / sum|.| %.1e" % (k, gen, n, E, D, kernel[:60], e3, e1, d13), flush=True)
+    print("case %2d: %-8s N=%6d E=%9d D=%3d dense %-10s %-60s err/bound lds %.3f gather %.3f  |lds - gather| / sum|.| %.1e" % (k, gen, n, E, D, dense, kernel[:60], e3, e1, d13), flush=True)
     assert e3 <= 1.0 and e1 <= 1.0, "outside the bound"
     TCGNN.clear_plan_cache()
     del rp, col, bp, e2c, e2r, X, att, Y1, Y3, Y64, absY; torch.cuda.empty_cache()
