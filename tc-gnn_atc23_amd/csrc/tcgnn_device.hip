@@ -842,7 +842,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                 const bool has_cold = cs.cold_tiles > 0 && !cs.d_wcold_ptr;
                 SpmmFlatArgs f{cs.d_flat, cs.d_order, x16, hdr, d_Y, plan->N, D, dpad / 16, passes[i].chunk0, plan->Nc + 1, plan->nw_eff, cs.nwg, g_lds_dbg,
                                has_cold ? 0 : relu, cs.d_rbase, cs.d_rl2, std::max(cs.npairs, 1), d_W, D_out, accumulate, g_lds_fill_quota, cs.d_wcold_ptr, cs.d_wcold, fb};
-                HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream));
+                HIP_TRY(launch_flat_any(passes[i].maxw, passes[i].nt, cs.flat_tpc, f, passes[i].nchunks, stream, cs.dense_entries > 0));
                 if (has_cold && !(g_lds_dbg & 16)) {
                     const int cd = lds_chunk_dims(passes[i].maxw);
                     const int col0 = passes[i].chunk0 * cd, ncols = std::min(passes[i].nchunks * cd, dpad - col0);

@@ -17,9 +17,9 @@ TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
 os.dup2(sv, 1)
 meta = (rp, col, bp, e2c, e2r)
 X = torch.randn(n, D, device=dev)
-c.lib.tcgnn_set_spmm_mode(3)
+c.lib.tcgnn_set_spmm_mode(int(os.environ.get("MODE", "3")))   # MODE=0: the automatic choice
 TCGNN.forward(X, *meta); TCGNN.kernel_timing(*meta, max_calls=10)
-for _ in range(int(os.environ.get("WARM", "10"))): TCGNN.forward(X, *meta)
+for _ in range(int(os.environ.get("WARM", "100"))): TCGNN.forward(X, *meta)   # (past the ~50-launch transient that follows an idle stretch)
 TCGNN.kernel_timing(*meta)
 for _ in range(30): TCGNN.forward(X, *meta)
 t = TCGNN.kernel_timing(*meta)
@@ -29,4 +29,4 @@ if int(os.environ.get("TCGNN_LDS_DBG", "0")) & 16:
     print("cycles per range (%d ranges), rows = wavefronts of workgroup 0, columns = fill issue / multiply / wait / barrier (mean cycles), pad refills (total), longest multiply, longest wait, tiles (total)" % nr)
     y = y.reshape(16, 8); y[:, :4] /= nr
     print(np.round(y).astype(int))
-print("dbg=%s D=%d: %.3f ms (min %.3f)  %s" % (os.environ.get("TCGNN_LDS_DBG", "0"), D, np.median(t), np.min(t), TCGNN.plan_info(*meta)))
+print("dbg=%s D=%d: %.3f ms (min %.3f)  %s  %s" % (os.environ.get("TCGNN_LDS_DBG", "0"), D, np.median(t), np.min(t), TCGNN.last_kernel(*meta), TCGNN.plan_info(*meta)))
