@@ -160,8 +160,8 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
  * `stream`.  Idempotent; widths are independent.  No counterpart in the reference (its kernels re-derive their tiles per launch). */
 int tcgnn_plan_prepare(tcgnn_plan* plan, int32_t D, void* stream);
 /* The same for the EDGE-VALUED SpMM (tcgnn_spmm_val = TCGNN.forward_AGNN, gnn_conv.py:132,143): builds the single-edge cell stream of the
- * LDS-resident edge-valued walk where the plan takes that walk at width D (whole 64-column chunks on graphs the time model sends to
- * the LDS-resident kernel; nothing otherwise).  Call it BEFORE tcgnn_workspace_bytes: the answer then includes the per-call slot
+ * LDS-resident edge-valued walk where the plan takes that walk at width D (whole 64-column chunks, alone or followed by a remainder of
+ * 33 .. 48 columns - Reddit's 41 classes -, on graphs the time model sends to the LDS-resident kernel; nothing otherwise).  Call it BEFORE tcgnn_workspace_bytes: the answer then includes the per-call slot
  * values, and the first tcgnn_spmm_val of that width neither allocates nor synchronises nor takes the gather walk.  Synchronises
  * `stream`.  Idempotent. */
 int tcgnn_plan_prepare_val(tcgnn_plan* plan, int32_t D, void* stream);

@@ -788,7 +788,7 @@ def _lds_val_case(dev, T, monkeypatch, att_fn, x_scale=1.0, prepare=True, seed=3
     return Y, kernel, ref, Y64, absY
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 41, 112])   # (41 / 112: a three-plane remainder - one more pair of 32-column chunks, the fourth plane zeros)
 @pytest.mark.parametrize("dense_cols", ["1", "5000", None])
 def test_edge_valued_lds_walk_with_dense_entries(dev, T, D, dense_cols, monkeypatch, capfd):
     """r05: forward_AGNN on the flat single-edge stream WITH dense entries (a community's own column ranges hold ~20 tiles of edges

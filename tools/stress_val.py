@@ -16,7 +16,7 @@ worst = 0.0; taken = 0
 for k in range(cases):
     n = int(rng.integers(1500, 60000)); deg = float(rng.choice([8, 40, 150, 400])); skew = float(rng.choice([0.0, 0.4, 0.8]))
     nnz = int(min(n * deg, 12_000_000))
-    D = int(rng.choice([64, 128, 64, 128, 41, 100]))   # (the walk exists for whole 64-column groups)
+    D = int(rng.choice([64, 128, 64, 41, 112, 100]))   # (the walk exists for whole 64-column groups and a three-plane remainder behind them)
     gen = str(rng.choice(["uniform", "uniform", "sbm", "rmat"]))
     seed_ = int(rng.integers(1 << 30))
     if gen == "uniform": rp, col = G.synthetic_csr(n, nnz, seed=seed_, device=dev, skew=skew)
