@@ -193,7 +193,9 @@ int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode);
  *      more launch scans the edges and recomputes, in fp32 with the reference's operand rounding, exactly the edges that touch a
  *      dirty row (scores, their share of the aggregate and of d_w): ~0.2 ms of scan plus a wavefront's work per such edge when it
  *      happens, a launch that returns at once when it does not.  Any number of dirty rows (r04 patched at most 48 and left a matrix
- *      with more - hub rows of a power-law graph under unscaled weights - to the bound above: closed in r05);
+ *      with more - hub rows of a power-law graph under unscaled weights - to the bound above: closed in r05).  On a structurally
+ *      symmetric graph (checked once, at plan creation) up to 256 dirty rows are patched without the scan: a dirty row's own edges
+ *      and their mirrors, ~10 us - what a training epoch usually meets;
  *   3  strict: a wide matrix is computed in plain fp32, CSR order, by SDDMM and the fused AGNN pair as well (correct for any
  *      magnitudes, ~50x slower than the MFMA path on a Reddit-sized graph; level 2 gives the same guarantee at the cost of the dirty edges).
  * tcgnn_range_mode reports which way the LAST staged call on this workspace went: *wide_x = 1 if its feature matrix took the fp32

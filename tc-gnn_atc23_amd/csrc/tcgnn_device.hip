@@ -76,6 +76,7 @@ struct tcgnn_plan {
     double near_frac = 0;                // share of the condensed columns within num_cols / 16 rows of their window (locality_kernel)
     int32_t Nc = 0;                      // columns of A = rows of X (== N unless row-sharded)
     int32_t row_off = 0;                 // X row holding A's row 0 (row-sharded SDDMM)
+    int32_t* d_sym = nullptr;            // device word: 1 = structurally symmetric (symmetry_kernel at plan creation; canonical square plans only)
     int64_t E = 0, tc_blocks = 0, total_wb = 0, max_wb = 0;   // max_wb: wide blocks of the longest window
     int canonical = 0, waves = 1;
     int32_t max_degree = 0;              // longest row of A (max_degree_kernel at creation): the range guard's thresholds follow it
@@ -995,7 +996,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     const int guard_level = range_guard_of(plan);
     if (guard_level >= 2) {
         // a few dirty rows (what training produces): the MFMA kernel above ran, the edges that touch them are recomputed here
-        const PatchArgs pa{hdr, dirty_bitmap_of(ws, plan->Nc, D), plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, d_w, d_Y, d_absmax, dw_extra, plan->N, plan->Nc, D, plan->row_off, bwd ? 2 : 1, plan->E};
+        const PatchArgs pa{hdr, dirty_bitmap_of(ws, plan->Nc, D), plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, d_w, d_Y, d_absmax, dw_extra, plan->N, plan->Nc, D, plan->row_off, bwd ? 2 : 1, plan->E, plan->d_sym};
         // (many: the same launch does all the work in plain fp32 - wide_dense_body; one launch per call either way, returning at once
         //  unless the staged matrix is "wide")
         HIP_TRY(launch_wide_patch(pa, stream, partial, nwg));
@@ -1033,7 +1034,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
         (void)hipFree(cs.d_wcold_ptr); (void)hipFree(cs.d_wcold); (void)hipFree(cs.d_eidx); (void)hipFree(cs.d_cold_eidx); (void)hipFree(cs.d_eidx16); (void)hipFree(cs.d_cold_eidx16);
     }
-    (void)hipFree(plan->d_xwb_ptr); (void)hipFree(plan->d_xcols); (void)hipFree(plan->d_xmask); (void)hipFree(plan->d_xeidx);
+    (void)hipFree(plan->d_xwb_ptr); (void)hipFree(plan->d_xcols); (void)hipFree(plan->d_xmask); (void)hipFree(plan->d_xeidx); (void)hipFree(plan->d_sym);
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TCGNN_OK;
@@ -1162,6 +1163,19 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build: %s", hipGetErrorString(e)));
     if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
     p->canonical = flags[1] ? 0 : 1;
+    // Is the graph structurally symmetric?  (The range guard's patch walks a few dirty rows' edges AND their mirrors instead of scanning
+    // every column id, where it is: wide_patch_kernel.)  One thread per edge, a binary search each; the answer stays on the device.
+    if (p->canonical && num_rows == num_cols && row_offset == 0 && num_edges > 0) {
+        e = hipMalloc(&p->d_sym, sizeof(int32_t));
+        const int32_t one = 1;
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_sym, &one, sizeof one, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(symmetry_kernel, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, stream, d_nodePointer, d_edgeList, d_edgeToRow, num_edges, num_rows, p->d_sym);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (`one` lives on this frame)
+        if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "plan build (symmetry): %s", hipGetErrorString(e)));
+    }
     if (nw > 0) {
         unsigned long long* d_loc = nullptr;
         unsigned long long h_loc[2] = {0, 0};
@@ -1488,7 +1502,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     timer.stop();
     // (the range guard's fallback: returns at once unless X is "wide")
     if (range_guard_of(plan) >= 2) {   // a few dirty rows: the patch behind the MFMA kernel; many: the CSR fallback (each returns at once otherwise)
-        const PatchArgs pa{hdr, dirty_bitmap_of(ws, plan->Nc, D), plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, nullptr, nullptr, nullptr, nullptr, plan->N, plan->Nc, D, plan->row_off, 0, plan->E};
+        const PatchArgs pa{hdr, dirty_bitmap_of(ws, plan->Nc, D), plan->rowptr, plan->col, plan->e2r, d_X, x16, pitch, d_ef, nullptr, nullptr, nullptr, nullptr, plan->N, plan->Nc, D, plan->row_off, 0, plan->E, plan->d_sym};
         HIP_TRY(launch_wide_patch(pa, stream));
     }
     HIP_TRY(hipGetLastError());

@@ -1321,7 +1321,7 @@ def test_wide_range_inside_one_matrix_takes_the_fp32_fallback(dev, T):
         T.clear_plan_cache()
 
 
-@pytest.mark.parametrize("specks", [1, 5, 12, 300, -40])   # (300: far beyond r04's list of 48 rows; -40: 40 rows on a graph with hub rows, the hubs among them)
+@pytest.mark.parametrize("specks", [1, 5, 12, 300, -40, 1007, 1200])   # (300: far beyond r04's list of 48 rows; -40: 40 rows on a graph with hub rows, the hubs among them; 1007: 7 rows on a DIRECTED graph; 1200: 200 rows, symmetric)
 def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks):
     """r04: the default guard level covers SDDMM and the fused AGNN pair.  What training produces is a matrix
     of 1e4-sized activations with ONE element 2^28 below the maximum (tools/probe_training_ranges.py): the quadratic bound makes it
@@ -1333,9 +1333,16 @@ def test_a_few_lost_elements_are_patched_behind_the_mfma_kernels(dev, T, specks)
     # recomputes every edge that touches one, a wavefront per edge; hub rows (thousands of edges each) are no special case.
     assert T.range_mode is not None
     T.set_range_guard(2)
+    # r05, late: up to 256 dirty rows of a structurally SYMMETRIC square graph are patched row-driven (a dirty row's own edges + their mirrors by
+    # binary search) instead of by the scan over every column id: 1 / 5 / 12 / 200 rows take that way, 300 rows and the directed graph the scan
     hubs = specks < 0
-    specks = abs(specks)
-    rp, col = graphs.hub_rows_graph(2500, seed=77) if hubs else graphs.uniform_graph(4000, 100, seed=5)
+    directed = specks == 1007
+    specks = abs(specks) % 1000
+    rp, col = graphs.hub_rows_graph(2500, seed=77) if hubs else graphs.uniform_graph(4000, 100, seed=5, symmetric=not directed)
+    if directed:
+        import scipy.sparse as sp
+        a_ = sp.csr_matrix((np.ones(len(col), np.int8), col, rp), shape=(len(rp) - 1, len(rp) - 1))
+        assert (a_ != a_.T).nnz > 0
     (bp, e2c, e2r), meta = meta_for(dev, rp, col)
     n, D = len(rp) - 1, 64
     rng = np.random.default_rng(100 + specks)
