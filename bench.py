@@ -335,9 +335,11 @@ def single_gpu(args):
         host_sgt_ms = (time.perf_counter() - t0) * 1e3
         bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
         TCGNN.preprocess_gpu(col_d, rp_d, n, 16, 8, bp, e2c, e2r)  # warm (rocPRIM temp allocation)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        TCGNN.preprocess_gpu(col_d, rp_d, n, 16, 8, bp, e2c, e2r)
-        torch.cuda.synchronize(); dev_sgt_ms = (time.perf_counter() - t0) * 1e3
+        dev_sgt_ms = float("inf")
+        for _ in range(3):   # (the best of three: one run in a dozen benches read 95 ms against 5 - an allocation, not the translation)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            TCGNN.preprocess_gpu(col_d, rp_d, n, 16, 8, bp, e2c, e2r)
+            torch.cuda.synchronize(); dev_sgt_ms = min(dev_sgt_ms, (time.perf_counter() - t0) * 1e3)
     finally:
         sys.stdout.flush(); os.dup2(saved, 1); os.close(saved); os.close(devnull)
     sgt_equal = bool(torch.equal(bp.cpu(), bp_h) and torch.equal(e2c.cpu(), e2c_h) and torch.equal(e2r.cpu(), e2r_h))
