@@ -303,12 +303,16 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
  * tcgnn_agnn_supported() tells; otherwise the calls return TCGNN_ERR_UNSUPPORTED and the caller
  * uses the three separate entry points. */
 int tcgnn_agnn_supported(const tcgnn_plan* plan, int32_t D);
-int tcgnn_agnn_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef,
-                       uint32_t* d_ef_absmax, float* d_Y, int32_t D, void* d_workspace,
-                       size_t workspace_bytes, void* stream);
-int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef,
-                        const uint32_t* d_ef_absmax, float* d_G, float* d_dw, int32_t D,
-                        void* d_workspace, size_t workspace_bytes, void* stream);
+/* (r06, ADVICE r05: these two replace r04 / r05's tcgnn_agnn_forward / tcgnn_agnn_backward, whose d_ef_absmax grew from 1 word to 1 + N
+ *  words in r05 under an unchanged signature - a caller built against the older header would have been written 4 N bytes past its word.
+ *  The names are gone, so such a caller fails to resolve them; the new ones take the element count of d_ef_absmax and return
+ *  TCGNN_ERR_INVALID_ARG when it is below 1 + N.) */
+int tcgnn_agnn_pair_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef,
+                            uint32_t* d_ef_absmax, int64_t ef_absmax_words, float* d_Y, int32_t D, void* d_workspace,
+                            size_t workspace_bytes, void* stream);
+int tcgnn_agnn_pair_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef,
+                             const uint32_t* d_ef_absmax, int64_t ef_absmax_words, float* d_G, float* d_dw, int32_t D,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -461,9 +461,9 @@ def agnn_fused_forward(input, nodePointer, edgeList, attention_w, blockPartition
     with torch.cuda.device(dev):
         plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
         ws, ws_bytes = _workspace(plan, D, dev)
-        st = _c.lib.tcgnn_agnn_forward(plan, input.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), absmax.data_ptr(),
-                                       out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
-    _c.check(st, "tcgnn_agnn_forward")
+        st = _c.lib.tcgnn_agnn_pair_forward(plan, input.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), absmax.data_ptr(), absmax.numel(),
+                                            out.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_agnn_pair_forward")
     return [out, ef, absmax]
 
 
@@ -483,9 +483,9 @@ def agnn_fused_backward(d_output, nodePointer, edgeList, attention_w, ef, ef_abs
     with torch.cuda.device(dev):
         plan = _plan_for(nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow)
         ws, ws_bytes = _workspace(plan, D, dev)
-        st = _c.lib.tcgnn_agnn_backward(plan, d_output.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), ef_absmax.data_ptr(),
-                                        out.data_ptr(), d_w.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
-    _c.check(st, "tcgnn_agnn_backward")
+        st = _c.lib.tcgnn_agnn_pair_backward(plan, d_output.data_ptr(), attention_w.data_ptr(), ef.data_ptr(), ef_absmax.data_ptr(), ef_absmax.numel(),
+                                             out.data_ptr(), d_w.data_ptr(), D, ws, ws_bytes, _stream_handle(dev))
+    _c.check(st, "tcgnn_agnn_pair_backward")
     return [out, d_w]
 
 

@@ -503,6 +503,11 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
 // (more wavefronts thrash the L2 harder) - level with range-major's 1.45-1.48, so not kept either.
 // TCGNN_AGNN_SLICED (read per call: tests switch it): 0 per-window only, 1 the rule above, 2 sliced whenever possible, 16 two rounds.
 static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
+// (r06) the sliced walk takes the windows in their own order, rotated per XCD (AgnnArgs::rot), unless hub windows must start first
+static int agnn_rot(const tcgnn_plan* plan) {
+    const char* const env = test_knob("TCGNN_AGNN_ROT");
+    return (env ? atoi(env) : 1) && windows_balanced(plan) ? 1 : 0;
+}
 enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
 static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_out) {
     *nslices_out = 0;
@@ -804,7 +809,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
             AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, nullptr, const_cast<float*>(d_val), const_cast<uint32_t*>(hdr) + 1, ypart, partial,
                        plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, plan->nbuckets / ns, 0, plan->nw_eff, 0,
-                       image_is_big(plan->Nc, pitch), ns, 1, nullptr};
+                       image_is_big(plan->Nc, pitch), ns, 1, nullptr, agnn_rot(plan)};
             {
                 KernelTimer timer(plan, stream, "agnn_kernel (XCD-sliced, values only) + agnn_slice_sum_kernel");
                 HIP_TRY((launch_agnn<4, true, 0>(dpad / 16, a, ns * ((plan->nw_eff + 3) / 4), stream)));
@@ -920,7 +925,7 @@ static bool agnn_supported(const tcgnn_plan* plan, int32_t D) {
 
 static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_absmax, float* d_Y,
                     float* d_dw, int32_t D, void* ws, size_t ws_bytes, void* stream_v, bool bwd) {
-    const char* name = bwd ? "tcgnn_agnn_backward" : "tcgnn_agnn_forward";
+    const char* name = bwd ? "tcgnn_agnn_pair_backward" : "tcgnn_agnn_pair_forward";
     if (!plan || D < 1 || !d_w || !d_absmax || (bwd && !d_dw) || (plan->N > 0 && (!d_X || !d_Y)) || (plan->E > 0 && !d_ef))
         return fail(TCGNN_ERR_INVALID_ARG, "%s: null argument or D < 1", name);
     if (!agnn_supported(plan, D))
@@ -948,7 +953,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
                plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
-               image_is_big(plan->Nc, pitch), 0, 0, reinterpret_cast<int32_t*>(d_absmax + 1)};   // (the per-row exponents of the edge weights sit behind the max |ef| word)
+               image_is_big(plan->Nc, pitch), 0, 0, reinterpret_cast<int32_t*>(d_absmax + 1), 0};   // (the per-row exponents of the edge weights sit behind the max |ef| word)
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
@@ -964,6 +969,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
             a.nslices = nslices;
             a.gsel = plan->nbuckets / nslices;
             a.y = ypart;
+            a.rot = agnn_rot(plan);
             nwg = nslices * ((plan->nw_eff + 3) / 4);
             e = bwd ? launch_agnn<4, true, 0>(nt, a, nwg, stream) : launch_agnn<4, false, 0>(nt, a, nwg, stream);
             if (e == hipSuccess) {
@@ -1015,13 +1021,21 @@ extern "C" {
 
 int tcgnn_agnn_supported(const tcgnn_plan* plan, int32_t D) { return agnn_supported(plan, D) ? 1 : 0; }
 
-int tcgnn_agnn_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_ef_absmax, float* d_Y,
-                       int32_t D, void* ws, size_t ws_bytes, void* stream) {
+static int agnn_words_ok(const tcgnn_plan* plan, int64_t words, const char* name) {
+    if (plan && words < 1 + (int64_t)plan->N)
+        return fail(TCGNN_ERR_INVALID_ARG, "%s: d_ef_absmax holds %lld words, the call writes / reads 1 + N = %lld (max |ef| + one scale exponent per row)", name, (long long)words, 1 + (long long)plan->N);
+    return TCGNN_OK;
+}
+
+int tcgnn_agnn_pair_forward(const tcgnn_plan* plan, const float* d_X, const float* d_w, float* d_ef, uint32_t* d_ef_absmax, int64_t ef_absmax_words, float* d_Y,
+                            int32_t D, void* ws, size_t ws_bytes, void* stream) {
+    if (const int rc = agnn_words_ok(plan, ef_absmax_words, "tcgnn_agnn_pair_forward")) return rc;
     return run_agnn(plan, d_X, d_w, d_ef, d_ef_absmax, d_Y, nullptr, D, ws, ws_bytes, stream, false);
 }
 
-int tcgnn_agnn_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef, const uint32_t* d_ef_absmax,
-                        float* d_G, float* d_dw, int32_t D, void* ws, size_t ws_bytes, void* stream) {
+int tcgnn_agnn_pair_backward(const tcgnn_plan* plan, const float* d_dY, const float* d_w, const float* d_ef, const uint32_t* d_ef_absmax, int64_t ef_absmax_words,
+                             float* d_G, float* d_dw, int32_t D, void* ws, size_t ws_bytes, void* stream) {
+    if (const int rc = agnn_words_ok(plan, ef_absmax_words, "tcgnn_agnn_pair_backward")) return rc;
     return run_agnn(plan, d_dY, d_w, const_cast<float*>(d_ef), const_cast<uint32_t*>(d_ef_absmax), d_G, d_dw, D, ws, ws_bytes, stream, true);
 }
 
@@ -1463,7 +1477,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const Guard gsd = guard_sddmm(plan, D);
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0, 0};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream, ks <= 4 ? "sddmm_kernel" : "sddmm_wide_kernel");
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
@@ -1493,7 +1507,12 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
         //  up, 1.43 -> 2.11 ms at D = 64, where an XCD has ONE range; with four ranges per XCD, spread over the graph, the load evens
         //  out again: D = 128 2.48 -> 2.25 ms there; TCGNN_SDDMM_XCD=2 forces it)
         const int xknob = xenv ? atoi(xenv) : 1;
-        if (xknob && (xknob >= 2 || plan->near_frac <= 0.2 || nranges >= 4 * kXcdCount) && nranges % kXcdCount == 0 && nwg >= kXcdCount) { a.xcd = 1; nwg -= nwg % kXcdCount; }
+        // (r06: that was the walk's window order, not the graph - `order` in its XCD-contiguous form hands a persistent wavefront windows of
+        //  ONE eighth of the graph only, SddmmArgs::ident; with the windows taken in their own order every wavefront of an XCD is inside the
+        //  same community at the same time, heavy or light together.  TCGNN_RM_IDENT=0 restores the old order for A/B runs)
+        const char* const ienv = test_knob("TCGNN_RM_IDENT");
+        a.ident = (ienv ? atoi(ienv) : 1) && windows_balanced(plan) ? 1 : 0;
+        if (xknob && (xknob >= 2 || a.ident || plan->near_frac <= 0.2 || nranges >= 4 * kXcdCount) && nranges % kXcdCount == 0 && nwg >= kXcdCount) { a.xcd = 1; nwg -= nwg % kXcdCount; }
         e = launch_sddmm_ks<4, true>(ks, a, nwg, stream);
     } else {
         e = plan->waves == 4 ? launch_sddmm_ks<4, false>(ks, a, plan->nw_eff, stream) : launch_sddmm_ks<1, false>(ks, a, plan->nw_eff, stream);

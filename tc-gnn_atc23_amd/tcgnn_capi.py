@@ -67,8 +67,8 @@ SIGNATURES = {
     "tcgnn_spmm_staged": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "tcgnn_sddmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_agnn_supported": (ctypes.c_int, [_vp, _i32]),
-    "tcgnn_agnn_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
-    "tcgnn_agnn_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "tcgnn_agnn_pair_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "tcgnn_agnn_pair_backward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library disagree

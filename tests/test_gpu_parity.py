@@ -348,7 +348,7 @@ FUSED_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n40", "empty
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
 @pytest.mark.parametrize("D", [16, 64, 128, 7, 41, 96])
 def test_fused_agnn_products_equal_the_separate_calls_and_the_oracle(dev, T, case, D):
-    """tcgnn_agnn_forward / tcgnn_agnn_backward (one gather for SDDMM + edge-weighted SpMM) against
+    """tcgnn_agnn_pair_forward / tcgnn_agnn_pair_backward (one gather for SDDMM + edge-weighted SpMM) against
     (a) the oracle composed the way gnn_conv.py:125-153 composes the operators and (b) the separate HIP calls."""
     name, rp, col = case
     n, nnz = len(rp) - 1, len(col)

@@ -203,9 +203,11 @@ def test_shard_whose_feature_matrix_needs_64_bit_addresses():
         # the fused AGNN pair gathers through the same descriptor
         w = torch.tensor([0.5], device=dev)
         ws, nb = ops._workspace(D)
-        ef = torch.empty(tcol.numel(), device=dev); efm = torch.zeros(1, dtype=torch.int32, device=dev); Yf = torch.empty(rows, D, device=dev)
+        ef = torch.empty(tcol.numel(), device=dev); efm = torch.zeros(1 + rows, dtype=torch.int32, device=dev); Yf = torch.empty(rows, D, device=dev)   # (max |ef| + one scale exponent per row: include/tcgnn.h)
         if c.lib.tcgnn_agnn_supported(ops.plan, D):
-            c.check(c.lib.tcgnn_agnn_forward(ops.plan, X.data_ptr(), w.data_ptr(), ef.data_ptr(), efm.data_ptr(), Yf.data_ptr(), D, ws, nb, st), "agnn_forward")
+            # (a buffer sized for r04's one word is refused, not overrun)
+            assert c.lib.tcgnn_agnn_pair_forward(ops.plan, X.data_ptr(), w.data_ptr(), ef.data_ptr(), efm.data_ptr(), 1, Yf.data_ptr(), D, ws, nb, st) == 1   # TCGNN_ERR_INVALID_ARG
+            c.check(c.lib.tcgnn_agnn_pair_forward(ops.plan, X.data_ptr(), w.data_ptr(), ef.data_ptr(), efm.data_ptr(), efm.numel(), Yf.data_ptr(), D, ws, nb, st), "agnn_pair_forward")
             err["fused agnn ef"] = ((ef.double() - refe).abs() / scalee).max().item() / 2
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
