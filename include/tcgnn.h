@@ -175,10 +175,11 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * plain per-window kernel, 2 = range-blocked whenever the plan has a bucket table, 3 = the
  * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
  * plan was created without one), 4 = the single-launch fp32-MFMA kernel small graphs take automatically
- * (no staging pass; binary SpMM only).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the
- * initial value. */
+ * (no staging pass; binary SpMM only), 5 = the slice-synchronised range walk (r06: graphs whose communities exceed an XCD's L2 -
+ * taken automatically there; forced, it runs wherever the plan built its tables and falls back to automatic elsewhere; SDDMM and the
+ * fused AGNN pair follow the same switch).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
-/* The same switch for ONE plan: mode 0 .. 4 as above, -1 = follow the process-wide value (the default).  Two plans of one process may
+/* The same switch for ONE plan: mode 0 .. 5 as above, -1 = follow the process-wide value (the default).  Two plans of one process may
  * walk differently. */
 int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode);
 

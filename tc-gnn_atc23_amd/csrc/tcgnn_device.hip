@@ -91,6 +91,15 @@ struct tcgnn_plan {
     uint32_t* d_bptr = nullptr;   // [nw_eff][nbuckets + 1] tile offset of the first tile whose first column is in bucket >= k
     int32_t num_cus = 256;
     size_t bytes = 0;
+    // tables of the slice-synchronised range walk (tcgnn_sync_walk.inc; r06): graphs whose communities exceed an XCD's L2
+    struct SyncTables {
+        int32_t S = 0, R = 0, nwx = 0, kmax = 0, fb_shift = 0;
+        uint32_t* d_T = nullptr;     // [nw_eff][kmax + 1]
+        int32_t* d_nk = nullptr;     // [8 * R]
+        double hot_frac = 0, avg_k = 0;   // share of the tiles inside their slice's hot buckets; hot buckets per slice, weighted by tiles
+        int32_t max_k = 0;
+        bool ok = false;
+    } sync;
     // cell streams of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc), one per range length in use (lds_stream_of: 4 windows per
     // wavefront x 4 / 2 / 1 / 3 planes, 8 windows x 2 / 1 planes); nranges == 0: not built
     struct CellStream {   // published by build_lds_cells under its mutex; nranges is written last (release) and read first (acquire)
@@ -321,6 +330,7 @@ __device__ __forceinline__ half4 lds_read_tr16(const char* p) {
 #include "tcgnn_pack_stage.inc"
 
 #include "tcgnn_gather_spmm.inc"
+#include "tcgnn_sync_walk.inc"
 
 
 #include "tcgnn_small_spmm.inc"
@@ -383,6 +393,25 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
         default: return hipErrorInvalidValue;
     }
 #undef TCGNN_BLK_CASE
+}
+
+// windows owned by one wavefront of the slice-synchronised walk: 1024 windows per XCD in flight at 8 wavefronts per CU (NT > 4: 256 registers)
+static constexpr int sync_maxw(int nt, bool val) { return 4; }
+template <int NT, bool VAL>
+static hipError_t launch_sync_one(const SpmmSyncArgs& args, int nwg, int nchunks, hipStream_t stream) {
+    constexpr int MAXW = sync_maxw(NT, VAL);
+    const size_t lds = (size_t)4 * TileWalker<NT, VAL>::WAVE_LDS + 4096;
+    hipLaunchKernelGGL((spmm_sync_kernel<NT, MAXW, VAL>), dim3((unsigned)nwg, (unsigned)nchunks), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+static hipError_t launch_sync_any(bool val, int nt, const SpmmSyncArgs& args, int nwg, int nchunks, hipStream_t stream) {
+#define TCGNN_SYNC_CASE(n) case n: return val ? launch_sync_one<n, true>(args, nwg, nchunks, stream) : launch_sync_one<n, false>(args, nwg, nchunks, stream);
+    switch (nt) {
+        TCGNN_SYNC_CASE(1) TCGNN_SYNC_CASE(2) TCGNN_SYNC_CASE(3) TCGNN_SYNC_CASE(4)
+        TCGNN_SYNC_CASE(5) TCGNN_SYNC_CASE(6) TCGNN_SYNC_CASE(7) TCGNN_SYNC_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TCGNN_SYNC_CASE
 }
 
 template <int WAVES, bool BLOCKED>
@@ -606,6 +635,114 @@ static int stage_features(const tcgnn_plan* plan, const float* d_X, const float*
 }
 
 #include "tcgnn_lds_plan.inc"
+
+// ---- tables of the slice-synchronised range walk (tcgnn_sync_walk.inc), built at plan creation for graphs whose numbering has
+// locality (near_frac > 0.5: the walks that rely on it are the ones this one replaces) and whose windows are alike.  Two small kernels, one
+// histogram copied to the host (slices x fine buckets words), one table of (kmax + 1) words per window.  Any failure leaves sync.ok false:
+// the walk is an optional acceleration, the per-window walk needs nothing from here.
+static int build_sync_tables(tcgnn_plan* p, hipStream_t stream) {
+    tcgnn_plan::SyncTables& t = p->sync;
+    const int nw = p->nw_eff;
+    if (nw < kSyncXcds * 256 || !p->d_cols || p->total_wb < 1) return TCGNN_OK;
+    const char* const verbose = getenv("TCGNN_VERBOSE");
+    t.nwx = (nw + kSyncXcds - 1) / kSyncXcds;
+    t.S = kSyncSlice;
+    t.R = (t.nwx + t.S - 1) / t.S;
+    t.kmax = kSyncKmax;
+    const int nslices = kSyncXcds * t.R;
+    const int nfb0 = (int)((((int64_t)p->Nc + 1) >> kSyncFbShift0) + 1);
+    uint32_t* d_hist = nullptr;
+    std::vector<uint32_t> hist((size_t)nslices * nfb0);
+    hipError_t e = hipMalloc(&d_hist, hist.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, hist.size() * sizeof(uint32_t), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(sync_hist_kernel, dim3((unsigned)nw), dim3(64), 0, stream, p->d_wb_ptr, p->d_cols, nw, t.nwx, t.S, t.R, kSyncFbShift0, nfb0, d_hist);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hist.data(), d_hist, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_hist);
+    if (e != hipSuccess) { (void)hipGetLastError(); return TCGNN_OK; }
+    // hot buckets per slice: at least a quarter of a tile per window of the slice; coarser buckets until every slice's list fits
+    std::vector<int32_t> hot((size_t)nslices * t.kmax, 0x7fffffff >> 12), nk((size_t)nslices, 0);
+    int shift = -1;
+    double tiles_all = 0, tiles_hot = 0, k_weighted = 0;
+    for (int sh = 0; sh <= 5 && shift < 0; ++sh) {
+        const int nfb = (nfb0 + (1 << sh) - 1) >> sh;
+        bool fits = true;
+        tiles_all = tiles_hot = k_weighted = 0;
+        t.max_k = 0;
+        for (int s = 0; s < nslices && fits; ++s) {
+            const int x = s / t.R, r = s % t.R;
+            const int64_t lo = (int64_t)x * t.nwx + (int64_t)r * t.S, hi = std::min<int64_t>(std::min<int64_t>(lo + t.S, (int64_t)(x + 1) * t.nwx), nw);
+            const int64_t wins = std::max<int64_t>(hi - lo, 0);
+            const uint32_t thr = (uint32_t)std::max<int64_t>(wins / 4, 16);
+            int k = 0;
+            double all = 0, hsum = 0;
+            for (int b = 0; b < nfb; ++b) {
+                uint64_t c = 0;
+                for (int q = b << sh; q < std::min(nfb0, (b + 1) << sh); ++q) c += hist[(size_t)s * nfb0 + q];
+                all += (double)c;
+                if (c >= thr) {
+                    if (k == t.kmax) { fits = false; break; }
+                    hot[(size_t)s * t.kmax + k++] = b;
+                    hsum += (double)c;
+                }
+            }
+            nk[(size_t)s] = k;
+            t.max_k = std::max(t.max_k, k);
+            tiles_all += all; tiles_hot += hsum; k_weighted += all * k;
+        }
+        if (fits) shift = sh;
+    }
+    if (shift < 0 || tiles_all <= 0) {
+        if (verbose && atoi(verbose) > 0) fprintf(stderr, "[tcgnn] sync walk: hot buckets do not fit %d entries per slice at any bucket size: not built\n", t.kmax);
+        return TCGNN_OK;
+    }
+    t.fb_shift = kSyncFbShift0 + shift;
+    t.hot_frac = tiles_hot / tiles_all;
+    t.avg_k = k_weighted / tiles_all;
+    if (verbose && atoi(verbose) > 0)
+        fprintf(stderr, "[tcgnn] sync walk: %d slices of %d windows, buckets of %d rows, %.1f hot buckets per slice (max %d), %.0f %% of the tiles inside them\n", nslices, t.S,
+                1 << t.fb_shift, t.avg_k, t.max_k, 100.0 * t.hot_frac);
+    if (t.hot_frac < 0.5) return TCGNN_OK;
+    int32_t* d_hot = nullptr;
+    const size_t b_T = (size_t)nw * (t.kmax + 1) * sizeof(uint32_t);
+    e = hipMalloc(&d_hot, hot.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&t.d_nk, nk.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&t.d_T, b_T);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hot, hot.data(), hot.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.d_nk, nk.data(), nk.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const int64_t total = (int64_t)nw * (t.kmax + 1);
+        hipLaunchKernelGGL(sync_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p->d_wb_ptr, p->d_cols, nw, t.nwx, t.S, t.R, t.kmax, t.fb_shift, d_hot, t.d_nk, t.d_T);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (host vectors above must outlive the copies)
+    (void)hipFree(d_hot);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t.d_T); (void)hipFree(t.d_nk); t.d_T = nullptr; t.d_nk = nullptr; return TCGNN_OK; }
+    p->bytes += b_T + nk.size() * sizeof(int32_t);
+    t.ok = true;
+    return TCGNN_OK;
+}
+// The walk is taken when the rows a slice's hot buckets span do not fit an XCD's L2 (else the per-window walk already finds them there):
+// avg_k buckets of 2^fb_shift rows of `pitch_bytes` each against ~5 MB.  TCGNN_SYNC=0 never, 2 whenever the tables exist (tests).
+static constexpr size_t kSyncPhaseBytes = (size_t)2 << 20;   // image bytes of one phase
+static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode) {
+    if (!plan->sync.ok || (mode != 0 && mode != 5)) return false;
+    const char* const env = test_knob("TCGNN_SYNC");
+    const int knob = env ? atoi(env) : 1;
+    if (!knob) return false;
+    if (knob >= 2 || mode == 5) return true;
+    return has_locality(plan) && windows_balanced(plan) && plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 5.0 * 1048576.0;
+}
+static SyncArgs sync_args(const tcgnn_plan* plan, int pitch_bytes) {
+    const tcgnn_plan::SyncTables& t = plan->sync;
+    size_t phase = kSyncPhaseBytes;
+    if (const char* e = test_knob("TCGNN_RANGE_KB")) phase = (size_t)atol(e) << 10;
+    const int m = (int)std::max<size_t>(1, phase / ((size_t)pitch_bytes << t.fb_shift));
+    return SyncArgs{t.d_T, t.d_nk, t.kmax, std::min(m, t.kmax), t.S, t.R, t.nwx, 0, plan->nw_eff};
+}
 
 // columns one gather-walk launch may cover: the widest row whose pitch the structured descriptor can express, in whole
 // 128-column chunks.  Wider matrices go through the gather walks as independent column blocks (ld = the full row length).
@@ -892,6 +1029,25 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                                                                      // (edge values: two windows per wavefront instead of four; at Reddit's 30 MB image the per-window walk
                                                                                      //  in contiguous order is 6 % faster - 1.70 against 1.79 ms per call - so only images beyond the Infinity Cache's reach)
                                                                                      (!d_val || x16_bytes > ((size_t)64 << 20))));
+    // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round
+    if (!d_W && !a.big && sync_chosen(plan, pitch * 2, mode)) {
+        KernelTimer timer(plan, stream, "spmm_sync_kernel");
+        SpmmSyncArgs sa{a, sync_args(plan, pitch * 2)};
+        auto wgs = [&](int nt) {   // workgroups per launch: what holds a slice (S windows per XCD, 4 wavefronts x MAXW windows per workgroup), at most what is resident
+            const bool val = d_val != nullptr;
+            const int lds_wg = 4 * (2 * nt * 1024 + kPadBytes + (val ? 2048 : 0)) + 4096;
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, (160 * 1024) / lds_wg));
+            const int per_xcd = std::min((plan->sync.S + 4 * sync_maxw(nt, val) - 1) / (4 * sync_maxw(nt, val)), plan->num_cus / kSyncXcds * per_cu);
+            return kSyncXcds * std::max(per_xcd, 1);
+        };
+        for (int r = 0; r < plan->sync.R; ++r) {
+            sa.s.round = r;
+            if (nfull) { sa.base.chunk0 = 0; HIP_TRY(launch_sync_any(d_val != nullptr, 8, sa, wgs(8), nfull, stream)); }
+            if (rem) { sa.base.chunk0 = nfull; HIP_TRY(launch_sync_any(d_val != nullptr, rem, sa, wgs(rem), 1, stream)); }
+        }
+        timer.stop();
+        return wide_fallback();
+    }
     KernelTimer timer(plan, stream, blocked ? "spmm_blocked_kernel" : "spmm_kernel");
     if (blocked) {
         size_t range_bytes = kRangeTargetBytes;
@@ -1043,6 +1199,7 @@ int tcgnn_plan_destroy(tcgnn_plan* plan) {
     if (!plan) return TCGNN_OK;
     (void)hipFree(plan->d_wb_ptr); (void)hipFree(plan->d_order); (void)hipFree(plan->d_cols);
     (void)hipFree(plan->d_mask); (void)hipFree(plan->d_ebase); (void)hipFree(plan->d_bptr);
+    (void)hipFree(plan->sync.d_T); (void)hipFree(plan->sync.d_nk);
     for (auto& cs : plan->lds) {
         (void)hipFree(cs.d_cell_ptr); (void)hipFree(cs.d_cell_tiles); (void)hipFree(cs.d_order); (void)hipFree(cs.d_rbase); (void)hipFree(cs.d_rlist); (void)hipFree(cs.d_rl2);
         (void)hipFree(cs.d_cold_ptr); (void)hipFree(cs.d_cold_cols); (void)hipFree(cs.d_cold_mask); (void)hipFree(cs.d_parts); (void)hipFree(cs.d_flat);
@@ -1234,6 +1391,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
             p->bytes += b_bp;
         }
     }
+    if (has_locality(p) && windows_balanced(p)) (void)build_sync_tables(p, stream);
     // Cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc) when the time models pick that kernel for a
     // 64-column matrix: built now rather than inside the first call.  Other widths decide, and build, at their first call.
     // TCGNN_LDS_AUTO=0 disables the automatic choice.
@@ -1304,7 +1462,7 @@ int tcgnn_plan_prepare_val(tcgnn_plan* plan, int32_t D, void* stream_v) {
 }
 
 int tcgnn_plan_set_spmm_mode(tcgnn_plan* plan, int32_t mode) {
-    if (!plan || mode < -1 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_spmm_mode: null plan, or mode outside -1 (process-wide value) .. 4");
+    if (!plan || mode < -1 || mode > 5) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_plan_set_spmm_mode: null plan, or mode outside -1 (process-wide value) .. 5");
     plan->spmm_mode.store((int8_t)mode, std::memory_order_relaxed);
     return TCGNN_OK;
 }
@@ -1345,7 +1503,7 @@ int tcgnn_range_mode(const void* d_workspace, void* stream_v, int32_t* wide_x, i
 }
 
 int tcgnn_set_spmm_mode(int32_t mode) {
-    if (mode < 0 || mode > 4) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked), 3 (LDS-resident ranges) or 4 (single-launch fp32 kernel)");
+    if (mode < 0 || mode > 5) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_set_spmm_mode: 0 (auto), 1 (plain), 2 (range-blocked), 3 (LDS-resident ranges), 4 (single-launch fp32 kernel) or 5 (slice-synchronised range walk)");
     g_spmm_mode = mode;
     return TCGNN_OK;
 }
@@ -1477,7 +1635,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     const Guard gsd = guard_sddmm(plan, D);
     int rc = stage_features(plan, d_X, nullptr, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, false, nullptr, 0, false, nullptr, &gsd);
     if (rc) return rc;
-    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0, 0};
+    SddmmArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_ef, plan->N, plan->Nc, plan->row_off, dpad, pitch, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, image_is_big(plan->Nc, pitch), 0, 0, 0, SyncArgs{}};
     const int ks = (dpad + 31) / 32;
     KernelTimer timer(plan, stream, ks <= 4 ? "sddmm_kernel" : "sddmm_wide_kernel");
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
@@ -1485,8 +1643,20 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // and keeping it inside ~4 MB column ranges wins on the Reddit shape: D=16 1.14 -> 1.07 ms, D=32 1.38 -> 1.14,
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
     const bool blocked = ks <= 4 && plan->nbuckets > 0 && spmm_mode_of(plan) != 1 && (spmm_mode_of(plan) == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
-    hipError_t e;
-    if (blocked) {
+    hipError_t e = hipSuccess;
+    if (ks <= 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan))) {
+        // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round, bit-identical scores
+        plan->last_kernel.store("sddmm_kernel (slice-synchronised)", std::memory_order_relaxed);
+        a.use_sync = 1;
+        a.sync = sync_args(plan, pitch * 2);
+        const int lds_wg = 4 * sddmm_wave_lds(ks);
+        const int per_cu = std::max(1, std::min(ks <= 2 ? 4 : 3, (160 * 1024) / lds_wg));
+        const int nwg = kSyncXcds * std::max(1, std::min((plan->sync.S + 3) / 4, plan->num_cus / kSyncXcds * per_cu));
+        for (int r = 0; r < plan->sync.R && e == hipSuccess; ++r) {
+            a.sync.round = r;
+            e = launch_sddmm_ks<4, true>(ks, a, nwg, stream);
+        }
+    } else if (blocked) {
         // (r03, whole-line gathers: D = 64 1.26 / 1.24 ms at 4 / 8 MB ranges, 1.36 at 2 MB; D = 128 - an image of 60 MB - 2.33 at 2 MB,
         //  2.58 at 4 MB, 3.5 per-window; with XCD affinity 2.01 at 2 or 4 MB)
         size_t range_bytes = x16_bytes > ((size_t)32 << 20) ? 2 * kRangeTargetBytes : 4 * kRangeTargetBytes;

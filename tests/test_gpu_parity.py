@@ -169,6 +169,62 @@ def test_range_blocked_walk_matches_oracle_and_plain_walk(dev, T, D):
         assert_parity(out[mode][1], refv, Yv64, absYv, "spmm_val mode %d" % mode)
 
 
+@pytest.mark.parametrize("range_kb", ["256", "1024", None])
+@pytest.mark.parametrize("D", [16, 64, 41, 128])
+def test_slice_synchronised_walk_matches_oracle_and_plain_walk(dev, T, D, range_kb, monkeypatch, capfd):
+    """r06: the slice-synchronised range walk (tcgnn_sync_walk.inc) - per slice of an XCD's share of the windows a
+    list of hot column buckets, phases of a few buckets, one launch per slice round - forced (mode 5) on a community graph small enough
+    for the oracle: 16 communities of 2 500 rows, 90 % of the edges inside, N % 16 = 3, with one, two or every hot bucket per phase.
+    Binary and edge-valued SpMM against the oracle, fp64 and the per-window walk; SDDMM bit for bit equal to the per-window walk."""
+    import re
+    import tcgnn_capi as c
+    rp, col = graphs.community_graph(40003, 16, 60, 0.9, seed=31)
+    n, nnz = len(rp) - 1, len(col)
+    (bp, e2c, e2r), meta = meta_for(dev, rp, col)
+    rng = np.random.default_rng(D + 5)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    att = rng.standard_normal(nnz).astype(np.float32)
+    tX, tatt = to_dev(dev, X, att)
+    Xs = (X / np.sqrt(D)).astype(np.float32)
+    tXs = to_dev(dev, Xs)[0]
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    if range_kb:
+        monkeypatch.setenv("TCGNN_RANGE_KB", range_kb)
+    out = {}
+    try:
+        T.clear_plan_cache()
+        for mode in (1, 5):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            Y = T.forward(tX, *meta)[0]
+            k1 = T.last_kernel(*meta)
+            Yv = T.forward_AGNN(tX, meta[0], meta[1], tatt.view(1, -1), *meta[2:])[0]
+            k2 = T.last_kernel(*meta)
+            ef = T.forward_ef(tXs, *meta)[0]
+            k3 = T.last_kernel(*meta)
+            out[mode] = (Y.cpu().numpy(), Yv.cpu().numpy(), ef, (k1, k2, k3), T.forward(tX, *meta)[0])
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+    err = capfd.readouterr().err
+    stats = re.findall(r"sync walk: (\d+) slices of (\d+) windows, buckets of (\d+) rows, ([0-9.]+) hot buckets per slice \(max (\d+)\), (\d+) % of the tiles", err)
+    assert stats, err[-1500:]
+    assert float(stats[0][3]) >= 2 and int(stats[0][5]) >= 60, stats
+    assert out[5][3] == ("spmm_sync_kernel", "spmm_sync_kernel", "sddmm_kernel (slice-synchronised)"), out[5][3]
+    assert out[1][3][0] == "spmm_kernel", out[1][3]
+    Y64, absY = O.spmm_f64(X, rp, col)
+    Yv64, absYv = O.spmm_f64(X, rp, col, att)
+    ref = O.spmm(X, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    refv = O.spmm_val(X, rp, col, att, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    refe = O.sddmm(Xs, rp, col, bp, e2c, e2r, round_mode=O.ROUND_TF32)
+    ef64, efabs = O.sddmm_f64(Xs, rp, col)
+    for mode in (1, 5):
+        assert_parity(out[mode][0], ref, Y64, absY, "spmm mode %d" % mode)
+        assert_parity(out[mode][1], refv, Yv64, absYv, "spmm_val mode %d" % mode)
+    assert_parity(out[5][2].cpu().numpy(), refe, ef64, efabs, "sddmm slice-synchronised")
+    assert torch.equal(out[5][2], out[1][2])
+    assert torch.equal(out[5][4].cpu(), torch.from_numpy(out[5][0]))   # deterministic
+
+
 def test_metadata_from_reference_fixture_feeds_the_kernels(dev, T):
     """The five legacy arrays exactly as the reference's preprocess wrote them (golden fixture)."""
     f = np.load(os.path.join(GOLD, "sgt_powerlaw_n1000.npz"))
