@@ -395,13 +395,22 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
 #undef TCGNN_BLK_CASE
 }
 
-// windows owned by one wavefront of the slice-synchronised walk: 1024 windows per XCD in flight at 8 wavefronts per CU (NT > 4: 256 registers)
-static constexpr int sync_maxw(int nt, bool val) { return 4; }
+// windows owned by one wavefront of the slice-synchronised walk, and its tile buffers.  Up to 64 columns: 4 windows, two buffers, 16 wavefronts
+// per CU (the grid is cut to what holds a slice).  Beyond: ONE 8 KB buffer per wavefront and 2 windows (64 accumulator registers of 168; three
+// spill 34-44 words at 128 columns), so that twelve wavefronts fit a CU instead of eight - 768 windows per XCD in flight: the slice (kSyncSlice).
+// (the edge-valued kernel at 128 columns spills at 168 registers: it keeps two buffers and eight wavefronts of 3 windows - 768 again)
+static constexpr int sync_nbuf(int nt, bool val) { return nt <= 4 || (val && nt == 8) ? 2 : 1; }
+static constexpr int sync_maxw(int nt, bool val) { return nt <= 4 ? 4 : (sync_nbuf(nt, val) == 2 ? 3 : 2); }
+static constexpr int sync_wgs_per_cu(int nt, bool val) {
+    const int lds_wg = 4 * (sync_nbuf(nt, val) * nt * 1024 + kPadBytes + (val ? 2048 : 0)) + 4096;
+    const int by_lds = (160 * 1024) / lds_wg, by_regs = nt <= 4 ? 4 : (sync_nbuf(nt, val) == 1 ? 3 : 2);
+    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+}
 template <int NT, bool VAL>
 static hipError_t launch_sync_one(const SpmmSyncArgs& args, int nwg, int nchunks, hipStream_t stream) {
-    constexpr int MAXW = sync_maxw(NT, VAL);
-    const size_t lds = (size_t)4 * TileWalker<NT, VAL>::WAVE_LDS + 4096;
-    hipLaunchKernelGGL((spmm_sync_kernel<NT, MAXW, VAL>), dim3((unsigned)nwg, (unsigned)nchunks), dim3(256), lds, stream, args);
+    constexpr int MAXW = sync_maxw(NT, VAL), NBUF = sync_nbuf(NT, VAL);
+    const size_t lds = (size_t)4 * TileWalker<NT, VAL, NBUF>::WAVE_LDS + 4096;
+    hipLaunchKernelGGL((spmm_sync_kernel<NT, MAXW, VAL, NBUF>), dim3((unsigned)nwg, (unsigned)nchunks), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 static hipError_t launch_sync_any(bool val, int nt, const SpmmSyncArgs& args, int nwg, int nchunks, hipStream_t stream) {
@@ -727,14 +736,14 @@ static int build_sync_tables(tcgnn_plan* p, hipStream_t stream) {
 }
 // The walk is taken when the rows a slice's hot buckets span do not fit an XCD's L2 (else the per-window walk already finds them there):
 // avg_k buckets of 2^fb_shift rows of `pitch_bytes` each against ~5 MB.  TCGNN_SYNC=0 never, 2 whenever the tables exist (tests).
-static constexpr size_t kSyncPhaseBytes = (size_t)2 << 20;   // image bytes of one phase
+static constexpr size_t kSyncPhaseBytes = (size_t)3 << 20;   // image bytes of one phase (products shape, D = 128: 3.01 / 2.77 / 2.72 ms at 1 / 2 / 3 MB)
 static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode) {
     if (!plan->sync.ok || (mode != 0 && mode != 5)) return false;
     const char* const env = test_knob("TCGNN_SYNC");
     const int knob = env ? atoi(env) : 1;
     if (!knob) return false;
     if (knob >= 2 || mode == 5) return true;
-    return has_locality(plan) && windows_balanced(plan) && plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 5.0 * 1048576.0;
+    return has_locality(plan) && windows_balanced(plan) && plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 10.0 * 1048576.0;
 }
 static SyncArgs sync_args(const tcgnn_plan* plan, int pitch_bytes) {
     const tcgnn_plan::SyncTables& t = plan->sync;
@@ -946,7 +955,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
             float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
             AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, nullptr, const_cast<float*>(d_val), const_cast<uint32_t*>(hdr) + 1, ypart, partial,
                        plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, plan->nbuckets / ns, 0, plan->nw_eff, 0,
-                       image_is_big(plan->Nc, pitch), ns, 1, nullptr, agnn_rot(plan)};
+                       image_is_big(plan->Nc, pitch), ns, 1, nullptr, agnn_rot(plan), 0, SyncArgs{}};
             {
                 KernelTimer timer(plan, stream, "agnn_kernel (XCD-sliced, values only) + agnn_slice_sum_kernel");
                 HIP_TRY((launch_agnn<4, true, 0>(dpad / 16, a, ns * ((plan->nw_eff + 3) / 4), stream)));
@@ -1035,9 +1044,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         SpmmSyncArgs sa{a, sync_args(plan, pitch * 2)};
         auto wgs = [&](int nt) {   // workgroups per launch: what holds a slice (S windows per XCD, 4 wavefronts x MAXW windows per workgroup), at most what is resident
             const bool val = d_val != nullptr;
-            const int lds_wg = 4 * (2 * nt * 1024 + kPadBytes + (val ? 2048 : 0)) + 4096;
-            const int per_cu = std::max(1, std::min(nt <= 4 ? 4 : 2, (160 * 1024) / lds_wg));
-            const int per_xcd = std::min((plan->sync.S + 4 * sync_maxw(nt, val) - 1) / (4 * sync_maxw(nt, val)), plan->num_cus / kSyncXcds * per_cu);
+            const int per_xcd = std::min((plan->sync.S + 4 * sync_maxw(nt, val) - 1) / (4 * sync_maxw(nt, val)), plan->num_cus / kSyncXcds * sync_wgs_per_cu(nt, val));
             return kSyncXcds * std::max(per_xcd, 1);
         };
         for (int r = 0; r < plan->sync.R; ++r) {
@@ -1109,7 +1116,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     }
     AgnnArgs a{plan->d_wb_ptr, plan->d_order, plan->d_cols, plan->d_mask, plan->d_ebase, x16, hdr, d_w, d_ef, d_absmax, d_Y, partial,
                plan->N, plan->Nc, plan->row_off, dpad, D, pitch, plan->E, plan->rowptr, plan->d_bptr, plan->nbuckets, 0, 0, plan->nw_eff, 0,
-               image_is_big(plan->Nc, pitch), 0, 0, reinterpret_cast<int32_t*>(d_absmax + 1), 0};   // (the per-row exponents of the edge weights sit behind the max |ef| word)
+               image_is_big(plan->Nc, pitch), 0, 0, reinterpret_cast<int32_t*>(d_absmax + 1), 0, 0, SyncArgs{}};   // (the per-row exponents of the edge weights sit behind the max |ef| word)
     const int nt = dpad / 16;
     const size_t x16_bytes = ((size_t)plan->Nc + 1) * pitch * sizeof(_Float16);
     float* const ypart = reinterpret_cast<float*>(static_cast<char*>(ws) + workspace_bytes_for(plan->Nc, D) + agnn_partial_bytes(plan));
@@ -1118,10 +1125,27 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     // is the fastest form at D = 64 (1.45-1.48 against 1.74 per-window, 1.53 sliced) - agnn_walk picks it there; mode 2 forces it.
     const bool blocked = plan->nbuckets > 0 && (spmm_mode_of(plan) == 2 || (spmm_mode_of(plan) == 0 && walk == kAgnnRangeMajor)) && x16_bytes > 0 && !a.big;
     int nwg = plan->nw_eff;
+    // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round, each with its own
+    // run of d_w slots
+    // (the backward kernel beyond 96 columns owns its windows at ONE wavefront per SIMD - 256 registers do not hold two windows' accumulators, operands
+    //  and per-row exponents - and loses more than the walk returns there: products shape, D = 128, 4.10 -> 6.24 ms; it stays per-window unless forced)
+    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan)) && !(bwd && nt > 6 && spmm_mode_of(plan) != 5);
     {
-        KernelTimer timer(plan, stream, (sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel");
-        hipError_t e;
-        if (sliced && !blocked) {
+        KernelTimer timer(plan, stream, synced ? "agnn_kernel (slice-synchronised)" : ((sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel"));
+        hipError_t e = hipSuccess;
+        if (synced) {
+            a.use_sync = 1;
+            a.sync = sync_args(plan, pitch * 2);
+            const int lds_wg = 4 * agnn_wave_lds((nt + 1) / 2, bwd);
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 3 : ((bwd && nt > 6) ? 1 : 2), (160 * 1024) / lds_wg));
+            const int per_launch = kSyncXcds * std::max(1, std::min((plan->sync.S + 4 * kAgnnMaxW - 1) / (4 * kAgnnMaxW), plan->num_cus / kSyncXcds * per_cu));
+            for (int r = 0; r < plan->sync.R && e == hipSuccess; ++r) {
+                a.sync.round = r;
+                a.partial = partial + (size_t)r * per_launch;
+                e = bwd ? launch_agnn<4, true, kAgnnMaxW>(nt, a, per_launch, stream) : launch_agnn<4, false, kAgnnMaxW>(nt, a, per_launch, stream);
+            }
+            nwg = plan->sync.R * per_launch;   // (d_w slots: R x 768 workgroups at most, fewer than the windows the workspace counts - build_sync_tables wants 2048 of them)
+        } else if (sliced && !blocked) {
             a.nslices = nslices;
             a.gsel = plan->nbuckets / nslices;
             a.y = ypart;

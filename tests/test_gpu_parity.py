@@ -187,6 +187,8 @@ def test_slice_synchronised_walk_matches_oracle_and_plain_walk(dev, T, D, range_
     tX, tatt = to_dev(dev, X, att)
     Xs = (X / np.sqrt(D)).astype(np.float32)
     tXs = to_dev(dev, Xs)[0]
+    tdY = to_dev(dev, (rng.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32))[0]
+    tw = torch.tensor([0.7], device=dev)
     monkeypatch.setenv("TCGNN_VERBOSE", "1")
     if range_kb:
         monkeypatch.setenv("TCGNN_RANGE_KB", range_kb)
@@ -201,7 +203,10 @@ def test_slice_synchronised_walk_matches_oracle_and_plain_walk(dev, T, D, range_
             k2 = T.last_kernel(*meta)
             ef = T.forward_ef(tXs, *meta)[0]
             k3 = T.last_kernel(*meta)
-            out[mode] = (Y.cpu().numpy(), Yv.cpu().numpy(), ef, (k1, k2, k3), T.forward(tX, *meta)[0])
+            Yf, eff, efm = T.agnn_fused_forward(tXs, meta[0], meta[1], tw, *meta[2:])
+            k4 = T.last_kernel(*meta)
+            Gb, dw = T.agnn_fused_backward(tdY, meta[0], meta[1], tw, eff, efm, *meta[2:])
+            out[mode] = (Y.cpu().numpy(), Yv.cpu().numpy(), ef, (k1, k2, k3), T.forward(tX, *meta)[0], (Yf, eff, Gb, float(dw), k4))
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
         T.clear_plan_cache()
@@ -223,6 +228,13 @@ def test_slice_synchronised_walk_matches_oracle_and_plain_walk(dev, T, D, range_
     assert_parity(out[5][2].cpu().numpy(), refe, ef64, efabs, "sddmm slice-synchronised")
     assert torch.equal(out[5][2], out[1][2])
     assert torch.equal(out[5][4].cpu(), torch.from_numpy(out[5][0]))   # deterministic
+    # the fused AGNN pair on the same schedule: scores bit for bit those of the per-window walk, sums in another order
+    (Yf1, ef1, G1, dw1, _), (Yf5, ef5, G5, dw5, k5) = out[1][5], out[5][5]
+    assert k5 == "agnn_kernel (slice-synchronised)", k5
+    assert torch.equal(ef5, ef1) and torch.equal(ef5, out[1][2])
+    sy = float(Yf1.abs().max()) + 1.0
+    assert float((Yf5 - Yf1).abs().max()) <= 1e-5 * sy and float((G5 - G1).abs().max()) <= 1e-5 * (float(G1.abs().max()) + 1.0)
+    assert abs(dw5 - dw1) <= 1e-5 * (abs(dw1) + 1.0), (dw1, dw5)
 
 
 def test_metadata_from_reference_fixture_feeds_the_kernels(dev, T):

@@ -35,9 +35,11 @@ for D in [int(x) for x in os.environ.get("DIMS", "128,64").split(",")]:
         t1, Y = timed(lambda: TCGNN.forward(X, *meta)[0]); k1 = TCGNN.last_kernel(*meta)
         t2, Yv = timed(lambda: TCGNN.forward_AGNN(X, rp, col, att, bp, e2c, e2r)[0]); k2 = TCGNN.last_kernel(*meta)
         t3, ef = timed(lambda: TCGNN.forward_ef(X, *meta)[0]); k3 = TCGNN.last_kernel(*meta)
+        t4, (Yf, eff, efm) = timed(lambda: TCGNN.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r)); k4 = TCGNN.last_kernel(*meta)
+        t5, (Gb, dw) = timed(lambda: TCGNN.agnn_fused_backward(X, rp, col, w, eff, efm, bp, e2c, e2r))
         if mode == 1: ref = dict(Y=Y.clone(), Yv=Yv.clone(), ef=ef.clone())
-        print("  D=%3d mode %d kb %s: spmm %.3f (%s) | spmm_val %.3f (%s) | sddmm %.3f (%s) | maxdiff Y %.2e Yv %.2e ef-equal %s" % (
-            D, mode, kb, t1, k1, t2, k2, t3, k3, (Y - ref["Y"]).abs().max().item(), (Yv - ref["Yv"]).abs().max().item(), torch.equal(ef, ref["ef"])), flush=True)
+        print("  D=%3d mode %d kb %s: spmm %.3f (%s) | spmm_val %.3f (%s) | sddmm %.3f (%s) | maxdiff Y %.2e Yv %.2e ef-equal %s | fused fwd %.3f bwd %.3f (%s) dw %.6e" % (
+            D, mode, kb, t1, k1, t2, k2, t3, k3, (Y - ref["Y"]).abs().max().item(), (Yv - ref["Yv"]).abs().max().item(), torch.equal(ef, ref["ef"]), t4, t5, k4, float(dw)), flush=True)
     c.lib.tcgnn_set_spmm_mode(0)
     os.environ.pop("TCGNN_RANGE_KB", None)
     del X, ref

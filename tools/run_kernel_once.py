@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one of the three kernels a few times on the Reddit-shaped graph (for rocprofv3 --pmc passes).
-usage: run_kernel_once.py {spmm|spmm_val|sddmm|agnn_fwd|agnn_bwd} [D] [mode]"""
+usage: run_kernel_once.py {spmm|spmm_val|sddmm|agnn_fwd|agnn_bwd} [D] [mode]   (TCGNN_PROFILE_SHAPE=reddit|ogbn-products, TCGNN_PROFILE_GEN=uniform|sbm|sbm_reddit|rmat)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tc-gnn_atc23_amd")): sys.path.insert(0, p)
@@ -10,7 +10,7 @@ which = sys.argv[1]; D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 if len(sys.argv) > 3: c.lib.tcgnn_set_spmm_mode(int(sys.argv[3]))
 dev = torch.device("cuda:0")
 n, nnz, _, _ = G.SHAPES[os.environ.get("TCGNN_PROFILE_SHAPE", "reddit")]
-rp, col = G.synthetic_csr(n, nnz, seed=0, device=dev)
+rp, col = G.GENERATORS[os.environ.get("TCGNN_PROFILE_GEN", "uniform")](n, nnz, seed=0, device=dev)
 E = col.numel(); nw = (n + 15) // 16
 bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
 TCGNN.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
