@@ -111,7 +111,23 @@ int tcgnn_preprocess(const int32_t* edgeList, const int32_t* nodePointer, int32_
 
 /* Device SGT.  Same outputs as tcgnn_preprocess, all pointers DEVICE memory.  Finishes what the
  * reference's preprocess_gpu / fill_window only sketch (TCGNN.cpp:229-256,
- * TCGNN_kernel.cu:42-80).  Synchronises `stream` once to return *tc_blocks. */
+ * TCGNN_kernel.cu:42-80).
+ *
+ * tcgnn_preprocess_gpu_ws (r06) runs on CALLER scratch: d_workspace of at least
+ * tcgnn_preprocess_gpu_workspace_bytes(num_nodes, num_edges, blockSize_h) bytes, 256-byte aligned (sort keys / positions / flags /
+ * ranks of the num_edges edge slots plus rocPRIM's scratch: ~2.3 GB at Reddit size).  It allocates and frees NOTHING and synchronises
+ * `stream` ONCE, to read back 24 bytes - nodePointer[0], nodePointer[num_nodes], the largest column id and *tc_blocks.  (A graph with
+ * column ids beyond num_nodes - legal, the host path takes them too - is sorted a second time with every key bit: the only way to a
+ * second synchronisation.)  Malformed row pointers are reported (TCGNN_ERR_BAD_GRAPH) after that read-back; until then every index
+ * derived from them is clamped to the arrays.
+ * tcgnn_preprocess_gpu keeps the reference's shape (no scratch argument): it allocates the workspace with hipMalloc, calls the _ws
+ * form and frees it - what r01-r05 measured as 5 ms or 95 ms by the allocator's mood. */
+int tcgnn_preprocess_gpu_workspace_bytes(int32_t num_nodes, int64_t num_edges, int32_t blockSize_h, size_t* bytes);
+int tcgnn_preprocess_gpu_ws(const int32_t* d_edgeList, const int32_t* d_nodePointer,
+                            int32_t num_nodes, int64_t num_edges, int32_t blockSize_h,
+                            int32_t blockSize_w, int32_t* d_blockPartition, int64_t bp_len,
+                            int32_t* d_edgeToColumn, int32_t* d_edgeToRow, void* d_workspace,
+                            size_t workspace_bytes, int64_t* tc_blocks, void* stream);
 int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_nodePointer,
                          int32_t num_nodes, int64_t num_edges, int32_t blockSize_h,
                          int32_t blockSize_w, int32_t* d_blockPartition, int64_t bp_len,

@@ -11,6 +11,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <list>
 #include <tuple>
@@ -178,9 +179,13 @@ void preprocess_gpu(torch::Tensor edgeList, torch::Tensor nodePointer, int num_n
   TORCH_CHECK(edgeToColumn.numel() >= edgeList.numel() && edgeToRow.numel() >= edgeList.numel(), "edgeToColumn / edgeToRow are shorter than edgeList");
   DeviceGuard guard(edgeList.device());
   int64_t tc_blocks = 0;
-  tcgnn_check(tcgnn_preprocess_gpu(edgeList.data_ptr<int>(), nodePointer.data_ptr<int>(), num_nodes, edgeList.numel(), blockSize_h, blockSize_w,
-                                   blockPartition.data_ptr<int>(), blockPartition.numel(), edgeToColumn.data_ptr<int>(),
-                                   edgeToRow.data_ptr<int>(), &tc_blocks, current_stream(edgeList)), "tcgnn_preprocess_gpu");
+  // scratch from torch's caching allocator: the library call allocates nothing and synchronises once (tcgnn_preprocess_gpu_ws)
+  size_t need = 0;
+  tcgnn_check(tcgnn_preprocess_gpu_workspace_bytes(num_nodes, edgeList.numel(), blockSize_h, &need), "tcgnn_preprocess_gpu_workspace_bytes");
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(need, 256)}, torch::TensorOptions().dtype(torch::kUInt8).device(edgeList.device()));
+  tcgnn_check(tcgnn_preprocess_gpu_ws(edgeList.data_ptr<int>(), nodePointer.data_ptr<int>(), num_nodes, edgeList.numel(), blockSize_h, blockSize_w,
+                                      blockPartition.data_ptr<int>(), blockPartition.numel(), edgeToColumn.data_ptr<int>(),
+                                      edgeToRow.data_ptr<int>(), ws.data_ptr(), (size_t)ws.numel(), &tc_blocks, current_stream(edgeList)), "tcgnn_preprocess_gpu_ws");
   printf("TC_Blocks:\t%lld\nExp_Edges:\t%lld\n", (long long)tc_blocks, (long long)tc_blocks * 8 * 16);
   fflush(stdout);
 }

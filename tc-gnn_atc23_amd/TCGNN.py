@@ -284,10 +284,17 @@ def preprocess_gpu(edgeList, nodePointer, num_nodes, blockSize_h, blockSize_w, b
     n = _c._i64(0)
     dev = edgeList.device
     with torch.cuda.device(dev):
-        st = _c.lib.tcgnn_preprocess_gpu(edgeList.data_ptr(), nodePointer.data_ptr(), num_nodes, E, int(blockSize_h),
-                                         int(blockSize_w), blockPartition.data_ptr(), blockPartition.numel(),
-                                         edgeToColumn.data_ptr(), edgeToRow.data_ptr(), _c.ctypes.byref(n), _stream_handle(dev))
-    _c.check(st, "tcgnn_preprocess_gpu")
+        # the translation's scratch (sort keys, positions, flags, ranks, rocPRIM's own) comes from torch's caching allocator: the library call
+        # allocates nothing and synchronises once (include/tcgnn.h, tcgnn_preprocess_gpu_ws); a second translation of a graph this size
+        # finds the block in the cache
+        need = _c._sz(0)
+        _c.check(_c.lib.tcgnn_preprocess_gpu_workspace_bytes(num_nodes, E, int(blockSize_h), _c.ctypes.byref(need)), "tcgnn_preprocess_gpu_workspace_bytes")
+        ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
+        st = _c.lib.tcgnn_preprocess_gpu_ws(edgeList.data_ptr(), nodePointer.data_ptr(), num_nodes, E, int(blockSize_h),
+                                            int(blockSize_w), blockPartition.data_ptr(), blockPartition.numel(),
+                                            edgeToColumn.data_ptr(), edgeToRow.data_ptr(), ws.data_ptr(), ws.numel(), _c.ctypes.byref(n), _stream_handle(dev))
+        del ws   # (the call synchronised the stream: nothing still reads it)
+    _c.check(st, "tcgnn_preprocess_gpu_ws")
     _report(n.value)
 
 

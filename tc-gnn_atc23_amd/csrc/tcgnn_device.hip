@@ -42,6 +42,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -1257,6 +1258,17 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     const int nw = p->nw_eff;
     std::vector<int32_t> bp((size_t)std::max(nw, 1));
     auto bail = [&](int rc) { tcgnn_plan_destroy(p); return rc; };
+    // TCGNN_VERBOSE=2: where plan creation spends its time (each mark synchronises the stream: a measurement aid, not the product's behaviour)
+    const char* const venv = getenv("TCGNN_VERBOSE");
+    const bool vtime = venv && atoi(venv) >= 2;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!vtime) return;
+        (void)hipStreamSynchronize(stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[tcgnn] plan_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (nw > 0) {
         uint32_t* d_maxdeg = nullptr;   // the longest row: what the range guard's bound follows (guard_spmm)
         uint32_t h_maxdeg = 0;
@@ -1273,6 +1285,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "read blockPartition: %s", hipGetErrorString(e)));
         p->max_degree = (int32_t)std::min<uint32_t>(h_maxdeg, 0x7fffffffu);
     }
+    mark("blockPartition to the host");
     std::vector<int64_t> wb_ptr((size_t)nw + 1, 0);
     for (int w = 0; w < nw; ++w) {
         if (bp[(size_t)w] < 0) return bail(fail(TCGNN_ERR_BAD_GRAPH, "blockPartition[%d] = %d is negative", w, bp[(size_t)w]));
@@ -1330,6 +1343,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         }
     }
     p->waves = (nw > 0 && p->total_wb >= (int64_t)6 * nw) ? 4 : 1;
+    mark("window order (host)");
 
     const size_t n_wb = (size_t)std::max<int64_t>(p->total_wb, 1);
     const size_t b_ptr = ((size_t)nw + 1) * sizeof(int64_t), b_ord = (size_t)std::max(nw, 1) * sizeof(int32_t);
@@ -1358,6 +1372,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     if (e != hipSuccess) return bail(fail(TCGNN_ERR_HIP, "plan build: %s", hipGetErrorString(e)));
     if (flags[0]) return bail(fail(TCGNN_ERR_BAD_GRAPH, "edgeToColumn / edgeToRow / edgeList hold ids outside the window, blockPartition or node range"));
     p->canonical = flags[1] ? 0 : 1;
+    mark("allocate + pack_kernel");
     // Is the graph structurally symmetric?  (The range guard's patch walks a few dirty rows' edges AND their mirrors instead of scanning
     // every column id, where it is: wide_patch_kernel.)  One thread per edge, a binary search each; the answer stays on the device.
     if (p->canonical && num_rows == num_cols && row_offset == 0 && num_edges > 0) {
@@ -1371,6 +1386,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (`one` lives on this frame)
         if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "plan build (symmetry): %s", hipGetErrorString(e)));
     }
+    mark("symmetry_kernel");
     if (nw > 0) {
         unsigned long long* d_loc = nullptr;
         unsigned long long h_loc[2] = {0, 0};
@@ -1387,6 +1403,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
         p->near_frac = h_loc[1] ? (double)h_loc[0] / (double)h_loc[1] : 0.0;
         if (const char* v = getenv("TCGNN_VERBOSE")) if (atoi(v) > 0) fprintf(stderr, "[tcgnn] plan: %.0f %% of the condensed columns lie within num_cols / 16 rows of their window\n", 100.0 * p->near_frac);
     }
+    mark("locality_kernel");
     {   // column buckets for the range-blocked SpMM: only when windows are long (>= 2 tiles per bucket on
         // average) and numerous enough to fill the chip with one wavefront per 4 windows (below)
         hipDeviceProp_t prop;
@@ -1415,7 +1432,9 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
             p->bytes += b_bp;
         }
     }
+    mark("bucket table");
     if (has_locality(p) && windows_balanced(p)) (void)build_sync_tables(p, stream);
+    mark("sync-walk tables");
     // Cell stream of the LDS-resident column-range SpMM (tcgnn_lds_spmm.inc) when the time models pick that kernel for a
     // 64-column matrix: built now rather than inside the first call.  Other widths decide, and build, at their first call.
     // TCGNN_LDS_AUTO=0 disables the automatic choice.
@@ -1428,6 +1447,7 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
             if (rc) return bail(rc);
         }
     }
+    mark("LDS cell streams (64 columns)");
     *plan_out = p;
     return TCGNN_OK;
 }

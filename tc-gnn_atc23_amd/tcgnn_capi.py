@@ -41,6 +41,8 @@ SIGNATURES = {
     "tcgnn_last_error": (ctypes.c_char_p, []),
     "tcgnn_preprocess": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _i32]),
     "tcgnn_preprocess_gpu": (ctypes.c_int, [_i32p, _i32p, _i32, _i64, _i32, _i32, _i32p, _i64, _i32p, _i32p, ctypes.POINTER(_i64), _vp]),
+    "tcgnn_preprocess_gpu_workspace_bytes": (ctypes.c_int, [_i32, _i64, _i32, ctypes.POINTER(_sz)]),
+    "tcgnn_preprocess_gpu_ws": (ctypes.c_int, [_i32p, _i32p, _i32, _i64, _i32, _i32, _i32p, _i64, _i32p, _i32p, _vp, _sz, ctypes.POINTER(_i64), _vp]),
     "tcgnn_tile_stats": (ctypes.c_int, [_i32p, _i32p, _i32, _i32, _i32, ctypes.POINTER(TileStats), _i32]),
     "tcgnn_plan_create": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),
     "tcgnn_plan_create_sharded": (ctypes.c_int, [_i32p, _i32p, _i32p, _i32p, _i32p, _i32, _i32, _i32, _i64, _i32, _vp, ctypes.POINTER(_vp)]),

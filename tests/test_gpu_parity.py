@@ -354,6 +354,57 @@ def test_device_sgt_with_edge_arrays_longer_than_the_csr(dev, T, capfd):
         T.preprocess_gpu(tcol[: nnz - 5].contiguous(), trp, n, 16, 8, bp, e2c, e2r)
 
 
+def test_device_sgt_on_caller_scratch_allocates_nothing(dev, T):
+    """r06: tcgnn_preprocess_gpu_ws runs on caller scratch - no hipMalloc / hipFree inside the call (r05's
+    translation made ~10 of them, 1.8 GB at Reddit size, and read 95 ms instead of 5 whenever the driver had to map fresh memory).
+    Shown two ways: the device's free memory is the same before and after three calls, and the call succeeds with less free memory
+    left on the device than its scratch needs (an internal allocation of that size would fail).  Same outputs as the host path and as
+    the reference-shaped entry point, which allocates the scratch itself."""
+    import ctypes
+    import tcgnn_capi as c
+    rp, col = graphs.uniform_graph(200_003, 60, seed=41)
+    n, nnz = len(rp) - 1, len(col)
+    bp_h, e2c_h, e2r_h, total = graphs.host_sgt(rp, col)
+    trp, tcol = to_dev(dev, rp, col)
+    nw = (n + 15) // 16
+    bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(nnz, dtype=torch.int32, device=dev); e2r = torch.zeros(nnz, dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t(0)
+    c.check(c.lib.tcgnn_preprocess_gpu_workspace_bytes(n, nnz, 16, ctypes.byref(need)), "workspace_bytes")
+    assert need.value >= 4 * 4 * nnz
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    got = ctypes.c_int64(0)
+    call = lambda: c.lib.tcgnn_preprocess_gpu_ws(tcol.data_ptr(), trp.data_ptr(), n, nnz, 16, 8, bp.data_ptr(), nw, e2c.data_ptr(), e2r.data_ptr(), ws.data_ptr(), need.value, ctypes.byref(got), st)
+    c.check(call(), "first call")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(3):
+        c.check(call(), "call")
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    assert got.value == total
+    assert np.array_equal(bp.cpu().numpy(), bp_h) and np.array_equal(e2c.cpu().numpy(), e2c_h) and np.array_equal(e2r.cpu().numpy(), e2r_h)
+    # too small a workspace is refused, not overrun
+    assert c.lib.tcgnn_preprocess_gpu_ws(tcol.data_ptr(), trp.data_ptr(), n, nnz, 16, 8, bp.data_ptr(), nw, e2c.data_ptr(), e2r.data_ptr(), ws.data_ptr(), need.value - 256, ctypes.byref(got), st) == 5   # TCGNN_ERR_WORKSPACE
+    # under memory pressure: all but ~half the scratch size of the device's free memory taken
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info(dev)[0]
+    hog = torch.empty(free - need.value // 2, dtype=torch.uint8, device=dev)
+    try:
+        e2c.zero_()
+        c.check(call(), "call under memory pressure")
+        torch.cuda.synchronize()
+        assert np.array_equal(e2c.cpu().numpy(), e2c_h)
+        # (the reference-shaped entry point allocates its scratch: with this little memory left it reports the failure instead of crashing)
+        assert c.lib.tcgnn_preprocess_gpu(tcol.data_ptr(), trp.data_ptr(), n, nnz, 16, 8, bp.data_ptr(), nw, e2c.data_ptr(), e2r.data_ptr(), ctypes.byref(got), st) == 3   # TCGNN_ERR_OOM
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    e2c.zero_()
+    c.check(c.lib.tcgnn_preprocess_gpu(tcol.data_ptr(), trp.data_ptr(), n, nnz, 16, 8, bp.data_ptr(), nw, e2c.data_ptr(), e2r.data_ptr(), ctypes.byref(got), st), "reference-shaped entry point")
+    assert got.value == total and np.array_equal(e2c.cpu().numpy(), e2c_h)
+
+
 def test_non_canonical_rows_take_the_fallback_kernels(dev, T):
     rp, col = graphs.uniform_graph(500, 12, seed=4)
     rng = np.random.default_rng(4)
