@@ -236,13 +236,17 @@ def artifact_shapes(seed, epochs=20):
                 # (the better of two 200-round averages: the first run after torch.cuda.empty_cache() pays the allocator's
                 #  hipMallocs inside its timed rounds - seen once as 0.127 ms against 0.019 on the PROTEINS_full shape)
                 k2 = H.run(H.build_parser().parse_args(base + ["--dim", "16", "--hidden", "16", "--single_kernel"]), quiet=True)
+                k_runs = [round(k["sag_ms"], 4), round(k2["sag_ms"], 4)]
                 if k2["sag_ms"] < k["sag_ms"]: k = k2
                 e = H.run(H.build_parser().parse_args(base + ["--dim", str(dim), "--hidden", "16", "--model", "gcn", "--epochs", str(epochs)]), quiet=True)
                 # (the better of two runs here too: these epochs are ~60 launches of a few microseconds, the host sets their time, and one
                 #  stall of the host inside twenty of them - seen once: 2.89 ms against 0.61 on the PROTEINS_full shape - is not the GPU's)
                 e2 = H.run(H.build_parser().parse_args(base + ["--dim", str(dim), "--hidden", "16", "--model", "gcn", "--epochs", str(epochs)]), quiet=True)
+                e_runs = [round(e["train_ms"], 3), round(e2["train_ms"], 3)]
                 if e2["train_ms"] < e["train_ms"]: e = e2
-            row.update({"nnz": k["nnz"], "spmm_d16_ms": round(k["sag_ms"], 4), "rtx3090_spmm_d16_ms": REF_RTX3090_KERNEL_MS[name],
+            # (both runs are recorded; the headline figure of a row is their minimum - `method`)
+            row.update({"spmm_d16_ms_runs": k_runs, "gcn_h16_ms_per_epoch_runs": e_runs, "method": "min of 2 runs",
+                        "nnz": k["nnz"], "spmm_d16_ms": round(k["sag_ms"], 4), "rtx3090_spmm_d16_ms": REF_RTX3090_KERNEL_MS[name],
                         "spmm_speedup_vs_rtx3090": round(REF_RTX3090_KERNEL_MS[name] / k["sag_ms"], 2),
                         "gcn_h16_ms_per_epoch": round(e["train_ms"], 3), "rtx3090_gcn_h16_ms_per_epoch": REF_RTX3090_GCN_EPOCH_MS[name],
                         "gcn_speedup_vs_rtx3090": round(REF_RTX3090_GCN_EPOCH_MS[name] / e["train_ms"], 2)})
@@ -440,17 +444,17 @@ def single_gpu(args):
         if reorder_ms is not None:
             row["reorder_ms"] = round(reorder_ms, 1)
         if "spmm" in ops:
-            leg = timed_leg(m_, E_, lambda: TCGNN.forward(X_, *m_), spmm_bytes(n_, E_, d), reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.forward(X_, *m_), spmm_bytes(n_, E_, d), reps=20)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
             row["spmm"] = leg
         if "spmm_val" in ops:
             att_ = torch.randn(1, E_, device=dev, generator=g)
-            leg = timed_leg(m_, E_, lambda: TCGNN.forward_AGNN(X_, rp_, col_, att_, bp_, e2c_, e2r_), spmm_bytes(n_, E_, d) + 4 * E_, reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.forward_AGNN(X_, rp_, col_, att_, bp_, e2c_, e2r_), spmm_bytes(n_, E_, d) + 4 * E_, reps=20)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"], val=True, bwd=True))
             row["spmm_val"] = leg
             del att_
         if "sddmm" in ops:
-            leg = timed_leg(m_, E_, lambda: TCGNN.forward_ef(X_, *m_), sddmm_bytes(n_, E_, d), reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.forward_ef(X_, *m_), sddmm_bytes(n_, E_, d), reps=20)
             leg.update(profile_fields(leg["kernel"], wl, 2.0 * E_ * d, leg["kernel_ms"]))
             row["sddmm"] = leg
         if "agnn" in ops:
@@ -458,10 +462,10 @@ def single_gpu(args):
             Xs_ = X_ / d ** 0.5
             _, ef_, efm_ = TCGNN.agnn_fused_forward(Xs_, rp_, col_, w_, bp_, e2c_, e2r_)
             pb = sddmm_bytes(n_, E_, d) + 4 * n_ * d
-            leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_forward(Xs_, rp_, col_, w_, bp_, e2c_, e2r_), pb, reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_forward(Xs_, rp_, col_, w_, bp_, e2c_, e2r_), pb, reps=20)
             leg.update(profile_fields(leg["kernel"], wl, 4.0 * E_ * d, leg["kernel_ms"], bwd=False))
             row["agnn_fused_fwd"] = leg
-            leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_backward(Xs_, rp_, col_, w_, ef_, efm_, bp_, e2c_, e2r_), pb, reps=10)
+            leg = timed_leg(m_, E_, lambda: TCGNN.agnn_fused_backward(Xs_, rp_, col_, w_, ef_, efm_, bp_, e2c_, e2r_), pb, reps=20)
             leg.update(profile_fields(leg["kernel"], wl, 4.0 * E_ * d, leg["kernel_ms"], bwd=True))
             row["agnn_fused_bwd"] = leg
             del ef_, efm_, Xs_
@@ -491,8 +495,8 @@ def single_gpu(args):
         del ef_s, efm_s
         for d2 in (16, 128):
             X2 = torch.randn(n, d2, device=dev, generator=g)
-            extra["spmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward(X2, *meta), spmm_bytes(n, E, d2), reps=10)
-            extra["sddmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward_ef(X2, *meta), sddmm_bytes(n, E, d2), reps=10)
+            extra["spmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward(X2, *meta), spmm_bytes(n, E, d2), reps=20)
+            extra["sddmm_d%d" % d2] = kernel_leg(lambda: TCGNN.forward_ef(X2, *meta), sddmm_bytes(n, E, d2), reps=20)
             del X2
         del att
         # ---- the same SpMM on a degree-skewed graph of the same size (real Reddit: max degree 21 657 at a mean of 492;
@@ -548,6 +552,16 @@ def single_gpu(args):
                  "N": n, "nnz": int(E), "D": D, "tc_blocks_16x8": info["tc_blocks"],
                  "spmm": {"kernel": kname, "kernel_ms": round(k_mean, 4), "gteps": round(gteps, 3), "hbm_frac": out["roofline"]["frac"],
                           **{k: out["roofline"][k] for k in ("traffic", "mfma_busy", "mfma_useful_frac", "mfma_useful_tflops", "mfma_peak_frac")}}}]
+    if not args.no_extra:
+        # (r06, VERDICT r05 item 7: the headline graph's row carries every operator with its PMC figures, not the SpMM alone - the legs
+        #  were timed above, the counters come from the same profile file)
+        wl0 = datasets[0]["workload"]
+        for key, src, val_, bwd_, fl in (("sddmm", "sddmm_d%d" % D, False, None, 2.0), ("spmm_val", "spmm_agnn_d%d" % D, True, True, 2.0),
+                                         ("agnn_fused_fwd", "agnn_fused_fwd_d%d" % D, False, False, 4.0), ("agnn_fused_bwd", "agnn_fused_bwd_d%d" % D, False, True, 4.0)):
+            leg = extra.get(src)
+            if isinstance(leg, dict) and leg.get("kernel"):
+                datasets[0][key] = dict(leg, **profile_fields(leg["kernel"], wl0, fl * E * D, leg["kernel_ms"], val=val_, bwd=bwd_))
+        datasets[0]["gcn_ms_per_epoch"] = extra.get("gcn_ms_per_epoch"); datasets[0]["agnn_ms_per_epoch"] = extra.get("agnn_ms_per_epoch")
     if not args.no_extra and args.scale == 1.0:
         TCGNN.clear_plan_cache()
         every = ("spmm", "spmm_val", "sddmm", "agnn")
@@ -833,7 +847,9 @@ def plan_only(args):
         widest = max(D, classes)
         feats = 4 * rows_r * in_dim
         acts = 4 * rows_r * (2 * D + 2 * classes) * 2                     # X W, A(X W) per layer, and their gradients
-        # ---- the exchange.  r05 default (tcgnn_shard.RowShard.spmm_chunked, exchange_chunk = 64): the matrix crosses the fabric 64
+        # ---- the exchange.  What RowShard.exchange_chunk_for picks at this size (r06: a whole-matrix receive buffer beyond 8 GiB - here
+        #      world * H * D * 4 bytes - takes tcgnn_shard.RowShard.spmm_chunked with 64 columns; smaller graphs keep the one gather,
+        #      whose total is reported next to it): the matrix crosses the fabric 64
         #      columns at a time as the kernels' fp16 image - every rank converts only its rows - into a ring of TWO image buffers
         #      that tcgnn_spmm_staged multiplies from; no fp32 copy of the gathered matrix exists.  Whole-matrix fp32 gather (r01-r04):
         #      one receive + send buffer pair per width in use and the image of the widest layer - reported next to it.
@@ -844,13 +860,17 @@ def plan_only(args):
         chunk_temps = 4 * rows_r * chunk + 2 * 4 * rows_r * widest          # the chunk's columns of X made contiguous; the chunks of Y and their concatenation
         parts = {"csr_bytes": csr, "sgt_metadata_bytes": sgt, "plan_bytes_est": plan, "exchange_image_ring_bytes": image_ring,
                  "exchange_send_ring_bytes": send_ring, "exchange_chunk_temporaries_bytes": chunk_temps, "features_bytes": feats, "layer_tensors_bytes": acts}
+        chunked_default = world * H * D * 4 > (8 << 30)
         total = sum(parts.values())
         image_w = 256 + (ncols + 1) * x16_pitch_halves((widest + 15) // 16 * 16) * 2
         gather_all = 4 * (ncols + H) * (D + classes)                      # one fp32 buffer pair per width used (D and the class layer)
         total_whole = csr + sgt + plan + image_w + gather_all + feats + acts
+        if not chunked_default:   # the default at this size is the one gather: that is the total that has to fit
+            total = total_whole = csr + sgt + plan + image_w + 4 * (ncols + H) * (D + classes) + feats + acts
         out_rows.append({"rank": r, "rows": rows_r, "edges": nnz_r, "gathered_rows": ncols, **parts,
                          "total_bytes": total, "parts_summed": sorted(parts), "frac_of_hbm": round(total / HBM_BYTES, 4), "fits": total < HBM_BYTES,
-                         "exchange": "64-column chunks, fp16 image on the wire, ring of two buffers (RowShard.spmm_chunked)",
+                         "exchange": ("64-column chunks, fp16 image on the wire, ring of two buffers (RowShard.spmm_chunked: the default at this size, RowShard.exchange_chunk_for)"
+                                      if chunked_default else "one fp32 gather of the whole matrix (the default at this size, RowShard.exchange_chunk_for); the parts listed are the chunked exchange's"),
                          "whole_matrix_fp32_exchange": {"image_fp16_widest_layer_bytes": image_w, "gather_buffers_all_widths_bytes": gather_all,
                                                         "total_bytes": total_whole, "frac_of_hbm": round(total_whole / HBM_BYTES, 4)}})
     H = per[0][2]
@@ -936,6 +956,13 @@ def compact_line(out, limit=LINE_LIMIT):
                         ("uniform_gcn_ms_per_epoch", row.get("gcn_ms_per_epoch")), ("uniform_agnn_ms_per_epoch", row.get("agnn_ms_per_epoch"))]
         if isinstance(row, dict) and row.get("workload", "").endswith("_rmat_d%s" % (D or "")) and isinstance(row.get("spmm"), dict):
             summary += [("rmat_spmm_ms", row["spmm"].get("kernel_ms")), ("rmat_spmm_agnn_ms", _leg(row.get("spmm_val")))]
+        if isinstance(row, dict) and row.get("workload") == "products_sbm_d128":
+            # r06: the community graph at ogbn-products size - communities of 12.5 MB, three times an XCD's L2: the
+            # slice-synchronised range walk (spmm_sync_kernel and its SDDMM / fused-forward forms)
+            summary += [("products_sbm_%s_ms" % op, _leg(row.get(op))) for op in ("spmm", "sddmm", "spmm_val", "agnn_fused_fwd", "agnn_fused_bwd")]
+            summary += [("products_sbm_spmm_kernel", clip(_leg(row.get("spmm"), "kernel"), 40)), ("products_sbm_spmm_traffic", _leg(row.get("spmm"), "traffic")),
+                        ("products_sbm_sddmm_traffic", _leg(row.get("sddmm"), "traffic")), ("products_sbm_spmm_frac", _leg(row.get("spmm"), "hbm_frac")),
+                        ("products_sbm_sddmm_frac", _leg(row.get("sddmm"), "hbm_frac"))]
         if isinstance(row, dict) and row.get("workload") == "products_uniform_d128":
             summary += [("products_d128_%s_ms" % op, _leg(row.get(op))) for op in ("spmm", "sddmm", "spmm_val")]
             summary += [("products_d128_sddmm_frac", _leg(row.get("sddmm"), "hbm_frac")), ("products_agnn_h128_ms_per_epoch", row.get("agnn_ms_per_epoch")),
@@ -948,6 +975,7 @@ def compact_line(out, limit=LINE_LIMIT):
     if sk:
         summary.append(("skewed_spmm_ms", _leg(ex[sk[0]])))
     summary += [("value_all_launches", out.get("value_all_launches")), ("host_sgt_ms", ex.get("host_sgt_ms")), ("device_sgt_ms", ex.get("device_sgt_ms")),
+                ("plan_create_ms", ex.get("plan_create_ms")),
                 ("device_sgt_equals_host_sgt", ex.get("device_sgt_equals_host_sgt")), ("plan_bytes", ex.get("plan_bytes")),
                 ("citeseer_spmm_d16_speedup_vs_rtx3090", ex.get("citeseer_spmm_d16_speedup_vs_rtx3090"))]
     beat = ex.get("artifact_shapes_beating_rtx3090")

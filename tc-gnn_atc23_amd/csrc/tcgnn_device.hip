@@ -1376,14 +1376,14 @@ int tcgnn_plan_create_sharded(const int32_t* d_nodePointer, const int32_t* d_edg
     // Is the graph structurally symmetric?  (The range guard's patch walks a few dirty rows' edges AND their mirrors instead of scanning
     // every column id, where it is: wide_patch_kernel.)  One thread per edge, a binary search each; the answer stays on the device.
     if (p->canonical && num_rows == num_cols && row_offset == 0 && num_edges > 0) {
-        e = hipMalloc(&p->d_sym, sizeof(int32_t));
-        const int32_t one = 1;
-        if (e == hipSuccess) e = hipMemcpyAsync(p->d_sym, &one, sizeof one, hipMemcpyHostToDevice, stream);
+        e = hipMalloc(&p->d_sym, 2 * sizeof(int32_t));   // [answer, (edges above the diagonal) - (edges below)]
+        static const int32_t sym_init[2] = {1, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(p->d_sym, sym_init, sizeof sym_init, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(symmetry_kernel, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, stream, d_nodePointer, d_edgeList, d_edgeToRow, num_edges, num_rows, p->d_sym);
-            e = hipGetLastError();
+            hipLaunchKernelGGL(symmetry_finish_kernel, dim3(1), dim3(1), 0, stream, p->d_sym);
+            e = hipGetLastError();   // (no synchronisation: nothing on the host waits for the answer - the patch kernels read it on the device)
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (`one` lives on this frame)
         if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "plan build (symmetry): %s", hipGetErrorString(e)));
     }
     mark("symmetry_kernel");

@@ -233,7 +233,13 @@ extern "C" int tcgnn_preprocess_gpu(const int32_t* d_edgeList, const int32_t* d_
     size_t bytes = 0;
     if (const int rc = tcgnn_preprocess_gpu_workspace_bytes(num_nodes, num_edges, blockSize_h > 0 ? blockSize_h : 1, &bytes)) return rc;
     void* ws = nullptr;
-    HIP_TRY(hipMalloc(&ws, bytes ? bytes : 1));
+    {
+        const hipError_t e = hipMalloc(&ws, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();   // (the runtime's sticky error word would otherwise surface in the caller's next, unrelated launch)
+            return fail(e == hipErrorOutOfMemory ? TCGNN_ERR_OOM : TCGNN_ERR_HIP, "tcgnn_preprocess_gpu: %zu bytes of scratch: %s (tcgnn_preprocess_gpu_ws takes caller scratch)", bytes, hipGetErrorString(e));
+        }
+    }
     const int rc = tcgnn_preprocess_gpu_ws(d_edgeList, d_nodePointer, num_nodes, num_edges, blockSize_h, blockSize_w, d_blockPartition, bp_len, d_edgeToColumn, d_edgeToRow,
                                            ws, bytes, tc_blocks, stream_v);
     (void)hipFree(ws);   // (the call above synchronised the stream)

@@ -158,20 +158,24 @@ class HipShardOps:
         rows, D = x_local.shape
         H, world = layout.H, layout.world
         pitch = c.lib.tcgnn_x16_pitch(D)
-        key = ("wire16", D, slot)
-        buf = getattr(self, "_wire", {}).get(key)
-        if buf is None:
-            image = torch.zeros(256 + (self.num_cols + 1) * pitch * 2 + 256, dtype=torch.uint8, device=dev)
-            off = (-image.data_ptr()) % 256
-            image = image[off: off + 256 + (self.num_cols + 1) * pitch * 2]
-            body = image[256:].view(torch.float16).view(self.num_cols + 1, pitch)
-            send = torch.zeros(H + 1, pitch, dtype=torch.float16, device=dev)
-            word = image[:4].view(torch.int32)
-            buf = (image, body, send, word)
-            if not hasattr(self, "_wire"):
-                self._wire = {}
-            self._wire[key] = buf
-        image, body, send, word = buf
+        # ONE buffer pair per ring slot, whatever the chunk's width (keyed by width, the 64 / 64 / 44 chunks of a 172-class
+        # layer held a third full image); a wider chunk than any seen so far replaces the pair
+        need_image, need_send = 256 + (self.num_cols + 1) * pitch * 2, (H + 1) * pitch * 2
+        if not hasattr(self, "_wire"):
+            self._wire = {}
+        raw = self._wire.get(slot)
+        if raw is None or raw[0].numel() < need_image + 256 or raw[1].numel() < need_send:
+            self._wire.pop(slot, None)
+            raw = (torch.zeros(need_image + 256, dtype=torch.uint8, device=dev), torch.zeros(need_send, dtype=torch.uint8, device=dev))
+            self._wire[slot] = raw
+        off = (-raw[0].data_ptr()) % 256
+        image = raw[0][off: off + need_image]
+        body = image[256:].view(torch.float16).view(self.num_cols + 1, pitch)
+        send = raw[1][:need_send].view(torch.float16).view(H + 1, pitch)
+        word = image[:4].view(torch.int32)
+        if getattr(self, "_wire_pitch", {}).get(slot) != pitch:   # (another width used this slot: rows nobody sends - padding, the sentinel - must be zero)
+            image.zero_(); send.zero_()
+            self._wire_pitch = dict(getattr(self, "_wire_pitch", {}), **{slot: pitch})
         collective = world > 1 or always_collective   # (a world of one can still run the collectives: bench.py's RCCL rehearsal)
         st = torch.cuda.current_stream(dev).cuda_stream
         x_local = x_local.contiguous()
@@ -262,8 +266,8 @@ class RowShard:
         same way) or `local=(local_row_pointers, global_column_ids)` + `bounds` when each rank only
         ever materialises its own rows (graphs too large for one host/GPU)."""
         self.group = group
-        # columns per exchange of `aggregate` / `exchange_spmm` (None: the whole matrix in one gather - the r01-r04 form; 64: the
-        # chunked exchange of spmm_chunked, what a graph of papers100M's size needs to fit - bench.py --plan-only)
+        # columns per exchange of `aggregate` / `exchange_spmm` (None: by size - exchange_chunk_for; 0: always the whole matrix in one
+        # gather, the r01-r04 form; 64: the chunked exchange of spmm_chunked, what a graph of papers100M's size needs to fit - bench.py --plan-only)
         self.exchange_chunk = exchange_chunk if exchange_chunk is not None else (int(os.environ["TCGNN_SHARD_EXCHANGE_CHUNK"]) if os.environ.get("TCGNN_SHARD_EXCHANGE_CHUNK") else None)
         # a world of one normally skips the exchange; with this switch it still issues every collective of the N-rank step
         # (all_gather_into_tensor of X / of the fp16 image slices, the one-word all_reduce(MAX)): how a 1-GPU box rehearses
@@ -434,10 +438,22 @@ class RowShard:
         main.wait_stream(side)
         return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 
+    # whole-matrix fp32 gather up to this many bytes of receive buffer; beyond it the exchange goes in 64-column chunks (the
+    # default has to be what bench.py --plan-only prices - a papers100M rank's 28 GB gather takes the chunked road, Reddit's 60 MB does not)
+    WHOLE_GATHER_MAX_BYTES = 8 << 30
+
+    def exchange_chunk_for(self, D):
+        """Columns per exchange of `aggregate` for a width: exchange_chunk when set (argument / TCGNN_SHARD_EXCHANGE_CHUNK; 0 = never chunk),
+        else 64 once the whole-matrix receive buffer would exceed WHOLE_GATHER_MAX_BYTES, else None (one gather)."""
+        if self.exchange_chunk is not None:
+            return self.exchange_chunk or None
+        return 64 if self.world * self.layout.H * D * 4 > self.WHOLE_GATHER_MAX_BYTES else None
+
     def exchange_spmm(self, x_local):
-        """What `aggregate` runs in either direction: the whole-matrix gather, or - exchange_chunk set - the chunked exchange."""
-        if self.exchange_chunk:
-            return self.spmm_chunked(x_local, self.exchange_chunk)
+        """What `aggregate` runs in either direction: the whole-matrix gather, or the chunked exchange (exchange_chunk_for)."""
+        chunk = self.exchange_chunk_for(x_local.shape[1])
+        if chunk:
+            return self.spmm_chunked(x_local, chunk)
         return self.ops.spmm(self.gather(x_local))
 
     def place_replicated(self, x_global):

@@ -453,6 +453,20 @@ def test_layers_with_hip_kernels_reproduce_reference_fixture(dev, T):
         b = f[key]
         return np.abs(t_.detach().cpu().numpy() - b).max() <= tol * max(1.0, np.abs(b).max())
     assert close_max(y, "agnn_Y") and close_max(x.grad, "agnn_dX") and close_max(w.grad, "agnn_dW")
+    # ... and ELEMENT BY ELEMENT against the oracle fed the kernel's own scores (r06, VERDICT r05 item 7: the fixture bound above is on the
+    # tensor's scale only).  With ef taken from the HIP path the rounding of att = a * ef cannot flip between the two sides, so every
+    # element of Y, of the aggregated gradient, of dX and of dW answers to the 1e-3 bar.
+    rp_h, col_h, bp_h, e2c_h, e2r_h = (f[k] for k in ("rowptr", "col", "bp", "e2c", "e2r"))
+    Ht = torch.mm(t("X"), t("W"))
+    ef_k = T.forward_ef(Ht, *meta)[0]
+    att_k = (t("attention_w").reshape(-1, 1) * ef_k.unsqueeze(0)).contiguous()
+    H_h, att_h = Ht.cpu().numpy(), att_k.reshape(-1).cpu().numpy()
+    ref_y = O.spmm_val(H_h, rp_h, col_h, att_h, bp_h, e2c_h, e2r_h, round_mode=O.ROUND_TF32)
+    ref_g = O.spmm_val(f["dY"], rp_h, col_h, att_h, bp_h, e2c_h, e2r_h, round_mode=O.ROUND_TF32)
+    elementwise = lambda got, ref: np.all(np.abs(got.detach().cpu().numpy() - ref) <= TOL * np.maximum(1.0, np.abs(ref)))
+    assert elementwise(y, ref_y)
+    assert elementwise(x.grad, (ref_g.astype(np.float64) @ f["W"].astype(np.float64).T))
+    assert elementwise(w.grad, (f["X"].astype(np.float64).T @ ref_g.astype(np.float64)))
     # d_attention_w = sum_e d_att[e] * col[e]: a signed 1180-term sum of O(100) terms; compare on the
     # scale of the terms, not of the (cancelling) result
     d_att = T.forward_ef(dY, *meta)[0]
@@ -1851,7 +1865,7 @@ def test_full_size_sbm_reddit_headline_graph_against_the_oracle(dev, T, capfd, m
     T.clear_plan_cache()
 
 
-def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary=False):
+def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary=False, extra_modes=(), must_include=None):
     """VERDICT r03 "oracle evidence at BASELINE size": the full-size tests above assert size-independent properties; here the SAME
     launches are compared with the ORACLE itself on a sample - `nwin` random row windows (16 rows each: 4 096 rows, ~1-2 M edges
     on the Reddit shape) evaluated by the oracle's own thread-block / warp bodies (oracle_spmm_windows / oracle_sddmm_windows =
@@ -1864,7 +1878,10 @@ def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary
     host = tuple(t.cpu().numpy() for t in meta)
     rng = np.random.default_rng(seed + D)
     nw = (n + 15) // 16
-    windows = np.sort(rng.choice(nw, size=min(nwin, nw), replace=False)).astype(np.int32)
+    windows = rng.choice(nw, size=min(nwin, nw), replace=False)
+    if must_include is not None:   # (e.g. the hub windows of a skewed graph: a random sample of 256 in 14 561 would miss them)
+        windows = np.union1d(windows, np.asarray(must_include))
+    windows = np.sort(windows).astype(np.int32)
     g = torch.Generator(device=dev).manual_seed(1000 + D + seed)
     X = torch.randn(n, D, device=dev, generator=g)
     att = torch.randn(E, device=dev, generator=g)
@@ -1931,7 +1948,7 @@ def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary
         assert_parity(G[trows].cpu().numpy(), Gref, G64, Ag64, "full-size fused G D=%d, %s" % (D, tag), unit_scale=False)
 
     try:
-        for mode, tag in ((0, "automatic"), (1, "per-window walk"), (2, "range-blocked / range-major walk")):
+        for mode, tag in ((0, "automatic"), (1, "per-window walk"), (2, "range-blocked / range-major walk")) + tuple(extra_modes):
             c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
             one_walk(tag)
         if lds_ordinary:   # the ordinary cell stream of the LDS-resident kernel (what graphs with communities or hubs take)
@@ -1947,6 +1964,50 @@ def _sampled_oracle_checks(dev, T, n, E, meta, D, nwin=256, seed=0, lds_ordinary
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
     return kernels
+
+
+def test_full_size_reddit_shape_with_hub_rows_against_the_oracle(dev, T):
+    """r06: the degree-skewed Reddit-sized graph bench.py times (`skewed_spmm_ms`: a ~24 k-degree hub at a mean of
+    492 - real Reddit: 21 657) had never been CHECKED at that size.  A @ 1 = degree exactly, and the oracle's window bodies on 128
+    random windows plus the eight heaviest (the hub rows' own), for the automatic kernels and both forced gather walks."""
+    import tcgnn_graph as G
+    n, nnz, _, _ = G.SHAPES["reddit"]
+    rp, col = G.synthetic_csr(n, nnz, seed=1, device=dev, skew=0.6)
+    E = col.numel()
+    nw = (n + 15) // 16
+    bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+    T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+    meta = (rp, col, bp, e2c, e2r)
+    deg = (rp[1:] - rp[:-1])
+    assert int(deg.max()) >= 20000
+    assert torch.equal(T.forward(torch.ones(n, 64, device=dev), *meta)[0], deg.float()[:, None].expand(-1, 64))
+    heavy = torch.topk(bp.float(), 8).indices.cpu().numpy()
+    _sampled_oracle_checks(dev, T, n, E, meta, 64, nwin=128, must_include=heavy)
+    T.clear_plan_cache()
+
+
+def test_full_size_ogbn_products_sbm_graph_on_the_slice_synchronised_walk(dev, T):
+    """r06: BASELINE.json configs[3]'s shape from the community generator (50 communities of 49 k rows, 90 % of the
+    edges inside: a community's image is 12.5 MB at D = 128, three times an XCD's L2) - the graph the slice-synchronised range walk was
+    built for.  The automatic mode takes it for SpMM, forward_AGNN, SDDMM and the fused forward pass; A @ 1 = degree exactly; and the
+    oracle's window bodies on 512 sampled windows for that walk, the per-window and range-blocked walks and the walk forced in both
+    directions of the fused pair (mode 5)."""
+    import tcgnn_graph as G
+    n, nnz, _, _ = G.SHAPES["ogbn-products"]
+    rp, col = G.GENERATORS["sbm"](n, nnz, seed=0, device=dev)
+    E = col.numel()
+    nw = (n + 15) // 16
+    bp = torch.zeros(nw, dtype=torch.int32, device=dev); e2c = torch.zeros(E, dtype=torch.int32, device=dev); e2r = torch.zeros(E, dtype=torch.int32, device=dev)
+    T.preprocess_gpu(col, rp, n, 16, 8, bp, e2c, e2r)
+    meta = (rp, col, bp, e2c, e2r)
+    deg = (rp[1:] - rp[:-1]).float()
+    assert torch.equal(T.forward(torch.ones(n, 128, device=dev), *meta)[0], deg[:, None].expand(-1, 128))
+    assert T.last_kernel(*meta) == "spmm_sync_kernel"
+    kernels = _sampled_oracle_checks(dev, T, n, E, meta, 128, nwin=512, extra_modes=((5, "slice-synchronised walk, forced"),))
+    assert kernels["automatic spmm"] == "spmm_sync_kernel" and kernels["automatic spmm_val"] == "spmm_sync_kernel", kernels
+    assert kernels["automatic sddmm"] == "sddmm_kernel (slice-synchronised)" and kernels["automatic fused fwd"] == "agnn_kernel (slice-synchronised)", kernels
+    assert kernels["slice-synchronised walk, forced fused bwd"] == "agnn_kernel (slice-synchronised)", kernels
+    T.clear_plan_cache()
 
 
 GEMM_CASES = [c for c in CASES if c[0] in ("uniform_n17", "uniform_n1000", "empty_middle_window_n48", "powerlaw_n1000", "citeseer_shape", "dense_n3000_deg150", "no_edges_n20")]

@@ -103,6 +103,10 @@ def _worker(rank, world, port, out_dir):
         xl3 = x_local.clone().requires_grad_(True)
         shard.aggregate(xl3).sum().backward()
         ok["chunked_autograd"] = torch.equal(yc.detach(), whole) and torch.equal(xl2.grad, xl3.grad)
+        # r06: unset, the chunk follows the SIZE of the whole-matrix receive buffer - what bench.py --plan-only prices
+        big = shard.WHOLE_GATHER_MAX_BYTES // (shard.world * shard.layout.H * 4) + 1
+        ok["chunk_default_by_size"] = (shard.exchange_chunk_for(D) is None and shard.exchange_chunk_for(big) == 64 and shard_c.exchange_chunk_for(big) == 16
+                                       and S.RowShard(rp, col, ops_factory=OracleShardOps, exchange_chunk=0).exchange_chunk_for(big) is None)
         # replicated placement (no exchange) gives the same gathered matrix as the collective
         ok["replicated"] = torch.equal(shard.place_replicated(torch.from_numpy(X)), shard.gather(x_local))
         # local-only construction (each rank materialises just its rows)
