@@ -173,9 +173,11 @@ class HipShardOps:
         body = image[256:].view(torch.float16).view(self.num_cols + 1, pitch)
         send = raw[1][:need_send].view(torch.float16).view(H + 1, pitch)
         word = image[:4].view(torch.int32)
-        if getattr(self, "_wire_pitch", {}).get(slot) != pitch:   # (another width used this slot: rows nobody sends - padding, the sentinel - must be zero)
+        if not hasattr(self, "_wire_pitch"):
+            self._wire_pitch = {}
+        if self._wire_pitch.get(slot) != pitch:   # (another width used this slot: rows nobody sends - padding, the sentinel - must be zero)
             image.zero_(); send.zero_()
-            self._wire_pitch = dict(getattr(self, "_wire_pitch", {}), **{slot: pitch})
+            self._wire_pitch[slot] = pitch
         collective = world > 1 or always_collective   # (a world of one can still run the collectives: bench.py's RCCL rehearsal)
         st = torch.cuda.current_stream(dev).cuda_stream
         x_local = x_local.contiguous()
