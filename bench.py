@@ -755,7 +755,29 @@ def multi_gpu(args):
     except Exception as exc:   # the extra leg must never take the headline down
         if rank == 0:
             print("sharded GCN leg failed: %s" % str(exc)[:300], file=sys.stderr)
-    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16, t_overlap, t_chunk], dtype=torch.float64, device=dev)
+    # ---- STRONG scaling next to the weak line above (r06): the single-GPU headline graph itself - args.graph at the
+    #      shape's own size, every rank builds the same seeded CSR - cut into N row blocks balanced by nnz (tcgnn_shard.partition_rows); X is
+    #      replicated (it fits one GPU: no collective in the step), a step is every rank's SpMM over its block, the time is
+    #      the slowest rank's.  value_strong = the WHOLE graph's edges over that time: N = 1 would read the single-GPU headline.
+    t_strong, e_strong, strong_kernel = float("nan"), 0.0, ""
+    try:
+        rp_g, col_g = G.GENERATORS[args.graph](n0, nnz0, seed=args.seed, device=dev)
+        shard_s = S.RowShard(rp_g.cpu().numpy(), col_g.cpu().numpy(), rank=rank, world_size=world, device=dev, always_collective=False)
+        del rp_g, col_g
+        xs = torch.randn(n0, D, device=dev, generator=torch.Generator(device=dev).manual_seed(args.seed))   # (the same matrix on every rank)
+        xg_s = shard_s.place_replicated(xs)
+        step_s = lambda: shard_s.ops.spmm(xg_s)
+        for _ in range(n_settle):
+            step_s()
+        torch.cuda.synchronize()
+        t_strong = sync_time(step_s, args.steps, args.warmup, barrier)
+        e_strong = float(shard_s.ops.nnz)
+        strong_kernel = str(_c.lib.tcgnn_plan_last_kernel(shard_s.ops.plan).decode()) if hasattr(_c.lib, "tcgnn_plan_last_kernel") else ""
+        del shard_s, xs, xg_s
+    except Exception as exc:   # an extra: must never take the headline down
+        if rank == 0:
+            print("strong-scaling leg failed: %s" % str(exc)[:300], file=sys.stderr)
+    stats = torch.tensor([elapsed, t_nox, float(E_local), float(np.mean(kernel_ms)), t_withx, gcn_ms, t_wire16, t_overlap, t_chunk, t_strong, e_strong], dtype=torch.float64, device=dev)
     mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     out = None
@@ -785,7 +807,13 @@ def multi_gpu(args):
                       "ms_per_step_with_overlapped_exchange": None if np.isnan(float(mx[7])) else round(float(mx[7]) * 1e3 / args.steps, 4),
                       "exchange_fraction_if_overlapped": None if np.isnan(float(mx[7])) else round(max(0.0, 1.0 - t_local / float(mx[7])), 4),
                       "ms_per_step_with_chunked_exchange_32col_fp32": None if np.isnan(float(mx[8])) else round(float(mx[8]) * 1e3 / args.steps, 4),
-                      "own_block_edge_fraction": round(float(getattr(shard, "_own_frac", float("nan"))), 4)},
+                      "own_block_edge_fraction": round(float(getattr(shard, "_own_frac", float("nan"))), 4),
+                      # strong scaling: the single-GPU headline graph split over the N ranks, X replicated (see above)
+                      "strong_scaling": None if np.isnan(float(mx[9])) else {
+                          "workload": "%s-shape graph from the %s generator, %d nodes, %d nnz in all, rows split over %d GPUs by nnz, X replicated" % (args.shape, args.graph, n0, int(sm[10]), world),
+                          "value_gteps": round(float(sm[10]) * args.steps / float(mx[9]) / 1e9, 3), "ms_per_step": round(float(mx[9]) * 1e3 / args.steps, 4),
+                          "kernel_rank0": strong_kernel, "scaling": "strong"},
+                      "value_strong_gteps": None if np.isnan(float(mx[9])) else round(float(sm[10]) * args.steps / float(mx[9]) / 1e9, 3)},
         }
     dist.barrier()
     dist.destroy_process_group()
@@ -982,7 +1010,7 @@ def compact_line(out, limit=LINE_LIMIT):
     if isinstance(beat, dict):
         summary.append(("artifact_shapes_beating_rtx3090", "%s/%s spmm_d16, %s/%s gcn_h16" % (beat.get("spmm_d16"), beat.get("of"), beat.get("gcn_h16_epoch"), beat.get("of"))))
     for k in ("exchange_in_timed_step", "ms_per_step_without_exchange", "exchange_fraction_if_exchanged", "gcn_ms_per_epoch_sharded",
-              "ms_per_step_with_fp16_exchange", "ms_per_step_with_overlapped_exchange", "ms_per_step_with_chunked_exchange_32col_fp32"):   # (the N > 1 line)
+              "ms_per_step_with_fp16_exchange", "ms_per_step_with_overlapped_exchange", "ms_per_step_with_chunked_exchange_32col_fp32", "value_strong_gteps"):   # (the N > 1 line)
         if k in ex:
             summary.append((k, ex[k]))
     summary = [(k, v) for k, v in summary if v is not None]

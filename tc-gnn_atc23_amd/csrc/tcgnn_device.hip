@@ -453,6 +453,16 @@ static hipError_t launch_agnn(int nt, const AgnnArgs& args, int nwg, hipStream_t
     return hipGetLastError();
 }
 
+// the fused backward kernel beyond 96 columns on the slice-synchronised walk: one window per wavefront (MAXW = 1)
+static hipError_t launch_agnn_wide_one(int nt, const AgnnArgs& args, int nwg, hipStream_t stream) {
+    const dim3 grid((unsigned)nwg), block(256);
+    const size_t lds = (size_t)4 * agnn_wave_lds((nt + 1) / 2, true);
+    if (nt == 7) hipLaunchKernelGGL((agnn_kernel<7, 4, true, 1>), grid, block, lds, stream, args);
+    else if (nt == 8) hipLaunchKernelGGL((agnn_kernel<8, 4, true, 1>), grid, block, lds, stream, args);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // ---- run-time switches.  Product: TCGNN_SPMM_MODE / TCGNN_RANGE_GUARD (initial values of tcgnn_set_spmm_mode / tcgnn_set_range_guard,
 // include/tcgnn.h) and TCGNN_VERBOSE (plan statistics on stderr).  TEST AIDS, read through test_knob() only - tests/ forces every walk
 // and layout through them against the oracle; no caller needs them: TCGNN_LDS_AUTO=0 (automatic mode never takes the LDS-resident
@@ -1130,7 +1140,8 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     // run of d_w slots
     // (the backward kernel beyond 96 columns owns its windows at ONE wavefront per SIMD - 256 registers do not hold two windows' accumulators, operands
     //  and per-row exponents - and loses more than the walk returns there: products shape, D = 128, 4.10 -> 6.24 ms; it stays per-window unless forced)
-    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan)) && !(bwd && nt > 6 && spmm_mode_of(plan) != 5);
+    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan));
+    const bool sync_one = bwd && nt > 6;   // (r06: ONE window per wavefront there - two wavefronts per SIMD, three trips per slice)
     {
         KernelTimer timer(plan, stream, synced ? "agnn_kernel (slice-synchronised)" : ((sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel"));
         hipError_t e = hipSuccess;
@@ -1138,12 +1149,13 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
             a.use_sync = 1;
             a.sync = sync_args(plan, pitch * 2);
             const int lds_wg = 4 * agnn_wave_lds((nt + 1) / 2, bwd);
-            const int per_cu = std::max(1, std::min(nt <= 4 ? 3 : ((bwd && nt > 6) ? 1 : 2), (160 * 1024) / lds_wg));
-            const int per_launch = kSyncXcds * std::max(1, std::min((plan->sync.S + 4 * kAgnnMaxW - 1) / (4 * kAgnnMaxW), plan->num_cus / kSyncXcds * per_cu));
+            const int per_cu = std::max(1, std::min(nt <= 4 ? 3 : 2, (160 * 1024) / lds_wg));
+            const int mw = sync_one ? 1 : kAgnnMaxW;
+            const int per_launch = kSyncXcds * std::max(1, std::min((plan->sync.S + 4 * mw - 1) / (4 * mw), plan->num_cus / kSyncXcds * per_cu));
             for (int r = 0; r < plan->sync.R && e == hipSuccess; ++r) {
                 a.sync.round = r;
                 a.partial = partial + (size_t)r * per_launch;
-                e = bwd ? launch_agnn<4, true, kAgnnMaxW>(nt, a, per_launch, stream) : launch_agnn<4, false, kAgnnMaxW>(nt, a, per_launch, stream);
+                e = !bwd ? launch_agnn<4, false, kAgnnMaxW>(nt, a, per_launch, stream) : (sync_one ? launch_agnn_wide_one(nt, a, per_launch, stream) : launch_agnn<4, true, kAgnnMaxW>(nt, a, per_launch, stream));
             }
             nwg = plan->sync.R * per_launch;   // (d_w slots: R x 768 workgroups at most, fewer than the windows the workspace counts - build_sync_tables wants 2048 of them)
         } else if (sliced && !blocked) {

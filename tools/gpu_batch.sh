@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r06i
-timeout 1700 python -m pytest tests -q -m gpu -rs > gpurun_out/r06i/gpu_tests.log 2>&1; tail -15 gpurun_out/r06i/gpu_tests.log
+mkdir -p gpurun_out/r06k
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "slice_synchronised" > gpurun_out/r06k/tests.log 2>&1; tail -3 gpurun_out/r06k/tests.log
+DIMS=128 KBS=3072 timeout 600 python tools/exp_r06b.py > gpurun_out/r06k/exp_sbm.log 2>&1; grep -v "^\[tcgnn\]" gpurun_out/r06k/exp_sbm.log | tail -4
