@@ -284,6 +284,20 @@ int tcgnn_spmm_gemm(const tcgnn_plan* plan, const float* d_X, const float* d_W, 
  *                        Only word 0 of the header is read (a staged image is never "wide": bytes 4 .. 255 are ignored and may hold
  *                        anything).  The image is READ-ONLY to the call: one image may feed several streams or ranks at once. */
 int tcgnn_x16_pitch(int32_t D);
+/* r06 - the same for the LDS-RESIDENT kernel, so that a row-sharded call keeps the fast walk.  That kernel reads a PLANAR image:
+ *   256-byte header (word 0 as above; words 1 .. 63 ZERO) followed by ceil(D / 16) planes of (num_cols + 1) records of 16 halves
+ *   (32 bytes): plane p, record r = columns 16 p .. 16 p + 15 of row r; record num_cols of every plane and all padding zero.
+ *   tcgnn_spmm_staged_layout : 1 if tcgnn_spmm would run the LDS-resident kernel on this plan at this width and can take a planar
+ *                              staged image (builds the width's cell streams if missing: may synchronise `stream` once), else 0 -
+ *                              stage row-major;
+ *   tcgnn_stage_rows_planar  : `rows` rows of X -> their records in every plane: d_dst = the slice's first record in plane 0,
+ *                              plane p lies plane_rows (= num_cols + 1) records further on per plane.  Writes nothing else;
+ *   tcgnn_spmm_staged_planar : Y = A_bin * X from such an image on the LDS-resident kernel (results identical to tcgnn_spmm in
+ *                              mode 3 on the same matrix); TCGNN_ERR_UNSUPPORTED where tcgnn_spmm_staged_layout says 0.
+ * A rank's slice of a plane is contiguous, so the exchange is one all-gather per plane. */
+int tcgnn_spmm_staged_layout(const tcgnn_plan* plan, int32_t D, void* stream);
+int tcgnn_stage_rows_planar(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, int64_t plane_rows, void* stream);
+int tcgnn_spmm_staged_planar(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream);
 int tcgnn_stage_absmax(const float* d_X, int64_t n, uint32_t* d_word, void* stream);
 int tcgnn_stage_rows(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, void* stream);
 int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream);

@@ -777,7 +777,7 @@ static bool val_lds_width_ok(const tcgnn_plan* plan, int dp) {
 }
 static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val, float* d_Y, int32_t D,
                     void* ws, size_t ws_bytes, void* stream_v, int relu = 0, const float* d_gate = nullptr, const void* d_staged = nullptr,
-                    int64_t ld = 0, bool block_of_wider = false, const float* d_W = nullptr, int32_t D_out = 0) {
+                    int64_t ld = 0, bool block_of_wider = false, const float* d_W = nullptr, int32_t D_out = 0, bool staged_planar = false) {
     if (!plan || D < 1 || (plan->N > 0 && ((!d_X && !d_staged) || !d_Y))) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm: null argument or D < 1");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (plan->N == 0) return TCGNN_OK;
@@ -800,7 +800,8 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
     }
     const uint32_t* hdr; const _Float16* x16; int dpad, pitch;
     // (the planar image is addressed as planes * rows 32-byte records through one buffer descriptor: 31 bits of record index)
-    bool lds = !d_val && !d_staged && !block_of_wider && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
+    // (a caller-staged image is row-major - the gather walks - unless it was staged PLANAR for this kernel: tcgnn_spmm_staged_planar, r06)
+    bool lds = !d_val && (!d_staged || staged_planar) && !block_of_wider && plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, round_up(D, 16)))) &&
                (int64_t)((D + 15) / 16) * ((int64_t)plan->Nc + 1) * 32 < ((int64_t)1 << 32);   // records * 32 B inside the descriptor's 32-bit offset
     // f3 on the LDS-resident kernel: one pass stores its product, the two 32-column passes of a 64-column matrix ADD theirs into a
     // zeroed Y (two addends: the sum does not depend on their order); wider inputs would need an ordered reduction - gather walk
@@ -856,7 +857,10 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         }
         else if (thin && mode != 3) { lds = false; if (round_up(D, 16) / 16 <= 64) plan->lds_choice[round_up(D, 16) / 16] = 0; }
         else if (any_cold) cold = &c0;
+        if (lds && cold && staged_planar) lds = false;   // (the remainder's gather walk wants a row-major image of the same matrix: not in a planar staged call)
     }
+    if (staged_planar && !lds)
+        return fail(TCGNN_ERR_UNSUPPORTED, "tcgnn_spmm_staged_planar: the LDS-resident kernel does not take this plan at %d columns (tcgnn_spmm_staged_layout tells; stage row-major and call tcgnn_spmm_staged)", D);
     if (!lds && !pitch_fits_descriptor(D)) {
         // a row too long for the gather walks' buffer descriptor: independent column blocks, every one rounded
         // with the scale of the whole matrix (absmax over all of X / the edge values here, once)
@@ -908,7 +912,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
         hdr = static_cast<const uint32_t*>(d_staged);
         x16 = reinterpret_cast<const _Float16*>(static_cast<const char*>(d_staged) + kHdrBytes);
         dpad = round_up(D, 16);
-        pitch = x16_pitch(dpad);
+        pitch = x16_pitch(dpad);   // (planar: [dpad / 16][Nc + 1][16] halves - the LDS branch below does not use the pitch)
     } else {
         const int rc = stage_features(plan, d_X, d_val, D, ws, ws_bytes, stream, &hdr, &x16, &dpad, &pitch, lds || val_lds, d_gate, block_of_wider ? ld : 0, block_of_wider);
         if (rc) return rc;
@@ -1669,6 +1673,50 @@ int tcgnn_spmm_staged(const tcgnn_plan* plan, const void* d_image, float* d_Y, i
     // bytes 4 .. 255 of the header: the image is READ-ONLY to this call, as the signature says - one staged image may be shared by
     // several streams or ranks (r04 cleared those words with a memset on the caller's image, a write racing with other readers).
     return run_spmm(plan, nullptr, nullptr, d_Y, D, nullptr, 0, stream, 0, nullptr, d_image);
+}
+
+// ---- r06: the staged image in the LDS-resident kernel's own (planar) layout, so that a row-sharded call keeps the fast kernel
+// (VERDICT r05 item 5).  Would tcgnn_spmm run the LDS-resident kernel on this plan at this width?  Builds the width's cell streams if
+// they are missing (synchronises once, like tcgnn_plan_prepare) and applies run_spmm's own conditions.
+static bool lds_takes_staged(const tcgnn_plan* plan, int32_t D, hipStream_t stream) {
+    const int mode = spmm_mode_of(plan);
+    const int dp = round_up(D, 16);
+    if (!(plan->nw_eff > 0 && (mode == 3 || (mode == 0 && lds_chosen(plan, dp))))) return false;
+    if ((int64_t)(dp / 16) * ((int64_t)plan->Nc + 1) * 32 >= ((int64_t)1 << 32)) return false;
+    LdsPass passes[2];
+    const int npass = lds_passes(dp, passes);
+    bool any_cold = false, thin = false;
+    for (int i = 0; i < npass; ++i) {
+        const int slot = lds_stream_of(passes[i].nt, passes[i].maxw);
+        if (plan->lds[slot].nranges == 0 && build_lds_cells(const_cast<tcgnn_plan*>(plan), stream, slot)) return false;
+        const tcgnn_plan::CellStream& ci = plan->lds[slot];
+        if (!ci.flat_tpc) any_cold = any_cold || ci.cold_tiles > 0;
+        thin = thin || ci.hot_cols * 2 < ci.hot_cols + ci.cold_cols;
+    }
+    return !any_cold && !(thin && mode != 3);
+}
+
+int tcgnn_spmm_staged_layout(const tcgnn_plan* plan, int32_t D, void* stream) {
+    if (!plan || D < 1) return 0;
+    return lds_takes_staged(plan, D, static_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
+int tcgnn_stage_rows_planar(const float* d_X, int32_t rows, int32_t D, const uint32_t* d_absmax_word, void* d_dst, int64_t plane_rows, void* stream_v) {
+    if (rows < 0 || D < 1 || (rows > 0 && !d_X) || !d_absmax_word || !d_dst || plane_rows < rows) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_rows_planar: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_dst) & 31) != 0) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_stage_rows_planar: destination must be 32-byte aligned");
+    const int nplanes = round_up(D, 16) / 16;
+    const int64_t chunks = (int64_t)rows * 2 * nplanes;
+    if (chunks > 0) {
+        hipLaunchKernelGGL(convert_planar_slice_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_v), d_X, rows, D, nplanes,
+                           static_cast<_Float16*>(d_dst), plane_rows, d_absmax_word);
+        HIP_TRY(hipGetLastError());
+    }
+    return TCGNN_OK;
+}
+
+int tcgnn_spmm_staged_planar(const tcgnn_plan* plan, const void* d_image, float* d_Y, int32_t D, void* stream) {
+    if (!d_image || (reinterpret_cast<uintptr_t>(d_image) & 255)) return fail(TCGNN_ERR_INVALID_ARG, "tcgnn_spmm_staged_planar: the image must be 256-byte aligned");
+    return run_spmm(plan, nullptr, nullptr, d_Y, D, nullptr, 0, stream, 0, nullptr, d_image, 0, false, nullptr, 0, true);
 }
 
 int tcgnn_spmm_val(const tcgnn_plan* plan, const float* d_X, const float* d_edge_val, float* d_Y, int32_t D,

@@ -67,6 +67,9 @@ SIGNATURES = {
     "tcgnn_stage_absmax": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "tcgnn_stage_rows": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "tcgnn_spmm_staged": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "tcgnn_spmm_staged_layout": (ctypes.c_int, [_vp, _i32, _vp]),
+    "tcgnn_stage_rows_planar": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "tcgnn_spmm_staged_planar": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "tcgnn_sddmm": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "tcgnn_agnn_supported": (ctypes.c_int, [_vp, _i32]),
     "tcgnn_agnn_pair_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),

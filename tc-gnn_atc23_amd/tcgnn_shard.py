@@ -147,7 +147,10 @@ class HipShardOps:
         c, dev = self.c, self.dev
         with torch.cuda.device(dev):
             Y = torch.empty(self.rows, D, device=dev)
-            c.check(c.lib.tcgnn_spmm_staged(self.plan, image.data_ptr(), Y.data_ptr(), D, torch.cuda.current_stream(dev).cuda_stream), "tcgnn_spmm_staged")
+            if getattr(image, "_tcgnn_planar", False):   # (r06: the image was staged in the LDS-resident kernel's own layout)
+                c.check(c.lib.tcgnn_spmm_staged_planar(self.plan, image.data_ptr(), Y.data_ptr(), D, torch.cuda.current_stream(dev).cuda_stream), "tcgnn_spmm_staged_planar")
+            else:
+                c.check(c.lib.tcgnn_spmm_staged(self.plan, image.data_ptr(), Y.data_ptr(), D, torch.cuda.current_stream(dev).cuda_stream), "tcgnn_spmm_staged")
         return Y
 
     def exchange_fp16(self, x_local, layout, rank, group=None, always_collective=False, slot=0):
@@ -157,6 +160,10 @@ class HipShardOps:
         c, dev = self.c, self.dev
         rows, D = x_local.shape
         H, world = layout.H, layout.world
+        with torch.cuda.device(dev):
+            planar = bool(c.lib.tcgnn_spmm_staged_layout(self.plan, D, torch.cuda.current_stream(dev).cuda_stream))
+        if planar:
+            return self._exchange_fp16_planar(x_local, layout, group, always_collective, slot)
         pitch = c.lib.tcgnn_x16_pitch(D)
         # ONE buffer pair per ring slot, whatever the chunk's width (keyed by width, the 64 / 64 / 44 chunks of a 172-class
         # layer held a third full image); a wider chunk than any seen so far replaces the pair
@@ -191,6 +198,49 @@ class HipShardOps:
                 all_gather_rows(body[: world * H].view(-1), send[:H].view(-1), group)
             else:
                 body[:H].copy_(send[:H])
+        return image
+
+    def _exchange_fp16_planar(self, x_local, layout, group, always_collective, slot):
+        """exchange_fp16 where the LDS-resident kernel takes this shard at this width (r06): the image is PLANAR -
+        ceil(D / 16) planes of (num_cols + 1) 32-byte records, include/tcgnn.h - a rank's rows are one contiguous run of every plane, and
+        the exchange is one all-gather per plane into that plane's first world * H records.  Same ring of two buffers, same abs-max word."""
+        c, dev = self.c, self.dev
+        rows, D = x_local.shape
+        H, world = layout.H, layout.world
+        P = (D + 15) // 16
+        need_image, need_send = 256 + P * (self.num_cols + 1) * 32, P * H * 32
+        if not hasattr(self, "_wire"):
+            self._wire = {}
+        raw = self._wire.get(slot)
+        if raw is None or raw[0].numel() < need_image + 256 or raw[1].numel() < need_send:
+            self._wire.pop(slot, None)
+            raw = (torch.zeros(need_image + 256, dtype=torch.uint8, device=dev), torch.zeros(need_send, dtype=torch.uint8, device=dev))
+            self._wire[slot] = raw
+        off = (-raw[0].data_ptr()) % 256
+        image = raw[0][off: off + need_image]
+        planes = image[256:].view(torch.float16).view(P, self.num_cols + 1, 16)
+        send = raw[1][:need_send].view(torch.float16).view(P, H, 16)
+        word = image[:4].view(torch.int32)
+        if not hasattr(self, "_wire_pitch"):
+            self._wire_pitch = {}
+        if self._wire_pitch.get(slot) != ("planar", P):   # (another layout used this slot: the header, the sentinel records and the padding must be zero)
+            image.zero_(); send.zero_()
+            self._wire_pitch[slot] = ("planar", P)
+        collective = world > 1 or always_collective
+        st = torch.cuda.current_stream(dev).cuda_stream
+        x_local = x_local.contiguous()
+        with torch.cuda.device(dev):
+            word.zero_()
+            c.check(c.lib.tcgnn_stage_absmax(x_local.data_ptr(), rows * D, word.data_ptr(), st), "tcgnn_stage_absmax")
+            if collective:
+                dist.all_reduce(word, op=dist.ReduceOp.MAX, group=group)
+            c.check(c.lib.tcgnn_stage_rows_planar(x_local.data_ptr(), rows, D, word.data_ptr(), send.data_ptr(), H, st), "tcgnn_stage_rows_planar")
+            for p in range(P):
+                if collective:
+                    all_gather_rows(planes[p, : world * H].reshape(-1), send[p].reshape(-1), group)
+                else:
+                    planes[p, :H].copy_(send[p])
+        image._tcgnn_planar = True
         return image
 
     def spmm_val(self, Xg, val):

@@ -40,7 +40,7 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ok, notes = {}, []
+    ok, notes, planar_seen = {}, [], []
     try:
         for gname, (rp, col) in (("powerlaw_n6000", graphs.powerlaw_graph(6000, 60, seed=5)), ("uniform_n20000", graphs.uniform_graph(20000, 48, seed=6))):
             n = len(rp) - 1
@@ -72,6 +72,21 @@ def _worker(rank, world, port, out_dir):
                         # r05: the exchange in column chunks (ring of two buffers, side stream) equals the whole-matrix one on the same walk
                         for ch, wr in ((16, "fp32"), (32, "fp32"), (64, "auto"), (32, "fp16")):
                             ok[tag + "chunked exchange %d cols / %s (mode %d)" % (ch, wr, mode)] = bool(torch.equal(a, shard.spmm_chunked(x_local, chunk=ch, wire=wr)))
+                    # r06: with the LDS-resident kernel forced the fp16 exchange stages the image PLANAR - one
+                    # all-gather per 16-column plane - and the shard keeps the fast kernel: bit for bit the fp32-gather call on that kernel
+                    c.check(c.lib.tcgnn_set_spmm_mode(3), "tcgnn_set_spmm_mode")
+                    planar = bool(c.lib.tcgnn_spmm_staged_layout(shard.ops.plan, D, torch.cuda.current_stream(dev).cuda_stream))
+                    a = shard.spmm(x_local)
+                    ka = c.lib.tcgnn_plan_last_kernel(shard.ops.plan).decode()
+                    b = shard.spmm(x_local, wire="fp16")
+                    kb = c.lib.tcgnn_plan_last_kernel(shard.ops.plan).decode()
+                    notes.append(tag + "mode 3: planar %s, kernels %s / %s" % (planar, ka, kb))
+                    if planar:
+                        ok[tag + "planar fp16 wire == fp32 wire on the LDS-resident kernel"] = bool(torch.equal(a, b)) and ka.startswith("spmm_lds") and kb.startswith("spmm_lds")
+                        ok[tag + "planar chunked exchange"] = bool(torch.equal(a[:, :min(D, 64)].contiguous(), shard.spmm_chunked(x_local[:, :min(D, 64)].contiguous(), chunk=64, wire="fp16"))) if D >= 64 else True
+                    else:
+                        ok[tag + "row-major fallback of the staged call (mode 3)"] = bool(((a - b).abs() / scale).max().item() <= TIGHT)
+                    planar_seen.append(planar)
                 finally:
                     c.lib.tcgnn_set_spmm_mode(0)
                 Yo = shard.spmm_overlapped(x_local)                      # gather on a side stream under the own-block product
@@ -94,6 +109,7 @@ def _worker(rank, world, port, out_dir):
             ok[gname + " backward through the exchange"] = bool(((xl.grad - ref).abs() / (ref.abs() + 10.0)).max().item() <= 1e-5)
             shard.ops.close()
 
+        ok["the planar staged image was exercised"] = any(planar_seen)
         # one whole sharded GCN training step on the HIP kernels vs the same step on the undivided graph (dense A, autograd)
         rp, col = graphs.powerlaw_graph(500, 12, seed=9)
         n, in_dim, hidden, classes = 500, 20, 16, 5
