@@ -399,12 +399,13 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
 // windows owned by one wavefront of the slice-synchronised walk, and its tile buffers.  Up to 64 columns: 4 windows, two buffers, 16 wavefronts
 // per CU (the grid is cut to what holds a slice).  Beyond: ONE 8 KB buffer per wavefront and 2 windows (64 accumulator registers of 168; three
 // spill 34-44 words at 128 columns), so that twelve wavefronts fit a CU instead of eight - 768 windows per XCD in flight: the slice (kSyncSlice).
-// (the edge-valued kernel at 128 columns spills at 168 registers: it keeps two buffers and eight wavefronts of 3 windows - 768 again)
-static constexpr int sync_nbuf(int nt, bool val) { return nt <= 4 || (val && nt == 8) ? 2 : 1; }
-static constexpr int sync_maxw(int nt, bool val) { return nt <= 4 ? 4 : (sync_nbuf(nt, val) == 2 ? 3 : 2); }
+// (r06, later: the single-buffer kernels walk their runs as ONE pipeline - TileWalker::walk_list - whose three list cursors do not fit the
+//  168 registers of twelve wavefronts at 7-8 tiles of width: eight wavefronts of 3 windows, 256 registers - 768 windows per XCD again)
+static constexpr int sync_nbuf(int nt, bool val) { return nt <= 4 ? 2 : 1; }
+static constexpr int sync_maxw(int nt, bool val) { return nt <= 4 ? 4 : 2; }
 static constexpr int sync_wgs_per_cu(int nt, bool val) {
-    const int lds_wg = 4 * (sync_nbuf(nt, val) * nt * 1024 + kPadBytes + (val ? 2048 : 0)) + 4096;
-    const int by_lds = (160 * 1024) / lds_wg, by_regs = nt <= 4 ? 4 : (sync_nbuf(nt, val) == 1 ? 3 : 2);
+    const int lds_wg = 4 * (sync_nbuf(nt, val) * nt * 1024 + kPadBytes + (val ? 2048 : 0) + (sync_nbuf(nt, val) == 1 ? 2048 : 0)) + 4096;
+    const int by_lds = (160 * 1024) / lds_wg, by_regs = nt <= 4 ? 4 : 2;
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 template <int NT, bool VAL>

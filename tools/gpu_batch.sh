@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r06l
-timeout 900 python -m pytest tests/test_gpu_sharded.py -x -q -m gpu > gpurun_out/r06l/tests.log 2>&1; tail -15 gpurun_out/r06l/tests.log
-TCGNN_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/r06l/bench_sharded.log 2> gpurun_out/r06l/bench_sharded.err; tail -c 1500 gpurun_out/r06l/bench_sharded.log; tail -5 gpurun_out/r06l/bench_sharded.err
+mkdir -p gpurun_out/r06m
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "slice_synchronised" > gpurun_out/r06m/tests.log 2>&1; tail -3 gpurun_out/r06m/tests.log
+DIMS=128 KBS=3072 timeout 600 python tools/exp_r06b.py > gpurun_out/r06m/exp_sbm.log 2>&1; grep -v "^\[tcgnn\]" gpurun_out/r06m/exp_sbm.log | tail -4
