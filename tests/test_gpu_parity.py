@@ -170,7 +170,7 @@ def test_range_blocked_walk_matches_oracle_and_plain_walk(dev, T, D):
 
 
 @pytest.mark.parametrize("range_kb", ["256", "1024", None])
-@pytest.mark.parametrize("D", [16, 64, 41, 128])
+@pytest.mark.parametrize("D", [16, 64, 41, 128, 96, 112])   # (96 / 112: the single-buffer run-list kernels at 6 and 7 tiles of width)
 def test_slice_synchronised_walk_matches_oracle_and_plain_walk(dev, T, D, range_kb, monkeypatch, capfd):
     """r06: the slice-synchronised range walk (tcgnn_sync_walk.inc) - per slice of an XCD's share of the windows a
     list of hot column buckets, phases of a few buckets, one launch per slice round - forced (mode 5) on a community graph small enough
