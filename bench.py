@@ -156,6 +156,9 @@ def load_profile(kernel, workload, val=None, bwd=None):
         # spmm_kernel / spmm_blocked_kernel exist with and without edge values (last template argument)
         if val is not None and name.split("<")[0] in ("spmm_kernel", "spmm_blocked_kernel") and name.rstrip(">").split(",")[-1].strip() != ("true" if val else "false"):
             continue
+        # spmm_sync_kernel<NT, MAXW, VAL, NBUF>
+        if val is not None and name.split("<")[0] == "spmm_sync_kernel" and name.rstrip(">").split(",")[2].strip() != ("true" if val else "false"):
+            continue
         # agnn_kernel<NT, WAVES, BWD, MAXW>: forward and backward are different instantiations (the edge-valued SpMM on the sliced walk
         # runs the backward one with its score half off: the collector's row averages over both uses)
         if bwd is not None and name.split("<")[0] == "agnn_kernel" and name.rstrip(">").split(",")[2].strip() != ("true" if bwd else "false"):
