@@ -433,7 +433,11 @@ class RowShard:
     # rank converts only ITS rows, the gathered buffer IS the kernels' image (tcgnn_spmm_staged) and no fp32 copy of the gathered
     # matrix exists at all: 2 x 14.2 GB instead of 118 + 42.6 GB per papers100M rank.  Results: a column of Y depends on that
     # column of X alone, and rounding to a 10-bit mantissa does not depend on the per-chunk power-of-two scale - so every chunk
-    # equals the same columns of the whole-matrix call on the same walk, bit for bit.
+    # equals the same columns of the whole-matrix call on the same walk, bit for bit, AS LONG AS no element falls below fp16's
+    # normal range under either scale (each chunk carries its own abs-max, so which elements of a matrix spanning
+    # more than 2^28 become subnormal or flush differs from the whole-matrix call).  And the range guard of tcgnn_spmm does NOT
+    # apply on the fp16 wire: a staged image has no fp32 matrix to fall back to (include/tcgnn.h, tcgnn_spmm_staged: "never
+    # wide") - a caller whose activations span that much keeps wire="fp32", whose chunks go through tcgnn_spmm and its guard.
     def spmm_chunked(self, x_local, chunk=64, wire="auto"):
         D = x_local.shape[1]
         chunk = max(16, int(chunk))
