@@ -22,8 +22,8 @@
  *   - Device pointers are BORROWED for the duration of the call (the plan borrows the five legacy
  *     arrays for its lifetime, see tcgnn_plan_create); outputs are caller-allocated.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All device
- *     work is enqueued asynchronously on it.  What synchronises the stream: tcgnn_plan_create and
- *     tcgnn_preprocess_gpu (to size their outputs), tcgnn_plan_prepare, and - ONLY for a feature width
+ *     work is enqueued asynchronously on it.  What synchronises the stream: tcgnn_plan_create (to size its
+ *     outputs), tcgnn_preprocess_gpu_ws (ONCE, to read back 24 bytes; it allocates nothing), tcgnn_plan_prepare, and - ONLY for a feature width
  *     tcgnn_plan_prepare was not called for - the first tcgnn_spmm / tcgnn_spmm_fused / tcgnn_spmm_gemm
  *     call of that width on a plan whose time model picks the LDS-resident kernel (it builds the
  *     width's cell stream: allocations, a few count-and-place round trips).  Call tcgnn_plan_prepare
@@ -192,8 +192,9 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
  * plan was created without one), 4 = the single-launch fp32-MFMA kernel small graphs take automatically
  * (no staging pass; binary SpMM only), 5 = the slice-synchronised range walk (r06: graphs whose communities exceed an XCD's L2 -
- * taken automatically there; forced, it runs wherever the plan built its tables and falls back to automatic elsewhere; SDDMM and the
- * fused AGNN pair follow the same switch).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the initial value. */
+ * taken automatically there - beyond 64 columns: the SpMM whenever the plan's tables exist, SDDMM and the fused AGNN pair where a
+ * slice's hot column buckets span more than ~10 MB of image; forced, it runs wherever the plan built its tables and falls back to the
+ * gather walks elsewhere; SDDMM and the fused AGNN pair follow the same switch).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
 /* The same switch for ONE plan: mode 0 .. 5 as above, -1 = follow the process-wide value (the default).  Two plans of one process may
  * walk differently. */

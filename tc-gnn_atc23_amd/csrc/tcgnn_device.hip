@@ -746,16 +746,23 @@ static int build_sync_tables(tcgnn_plan* p, hipStream_t stream) {
     t.ok = true;
     return TCGNN_OK;
 }
-// The walk is taken when the rows a slice's hot buckets span do not fit an XCD's L2 (else the per-window walk already finds them there):
-// avg_k buckets of 2^fb_shift rows of `pitch_bytes` each against ~5 MB.  TCGNN_SYNC=0 never, 2 whenever the tables exist (tests).
+// When the walk is taken (automatic mode; TCGNN_SYNC=0 never, 2 whenever the tables exist; mode 5 forces it).  Measured on the ogbn-products
+// shape with 25 / 50 / 100 / 200 communities (25 / 12.5 / 6.3 / 3.1 MB of image each at D = 128; tools/exp_r06d.py, kernel ms, per-window -> this walk):
+//   SpMM  D = 128   3.95 -> 3.15   3.65 -> 2.66   3.20 -> 2.52   3.02 -> 2.46     it wins at every size: beyond 64 columns whenever the tables exist
+//   SDDMM D = 128   4.00 -> 3.49   3.43 -> 2.89   2.56 -> 2.64   2.30 -> 2.51     only where the hot span of a slice (avg_k buckets) exceeds ~10 MB
+//   SpMM  D = 64    1.77 -> 2.27   1.49 -> 2.16   1.43 -> 2.09   1.38 -> 2.02     never: up to 64 columns the per-window walk's rows are one line each
+//   SDDMM D = 64    1.84 -> 1.95   1.71 -> 1.85   1.67 -> 1.77   1.64 -> 1.62     and a community's image is half the size
+// (the fused pair follows the SDDMM's rule: measured at 50 communities only, 4.15 / 4.03 -> 3.62 / 3.83).
+enum { kSyncSpmm = 0, kSyncScores = 1 };
 static constexpr size_t kSyncPhaseBytes = (size_t)3 << 20;   // image bytes of one phase (products shape, D = 128: 3.01 / 2.77 / 2.72 ms at 1 / 2 / 3 MB)
-static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode) {
+static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode, int op) {
     if (!plan->sync.ok || (mode != 0 && mode != 5)) return false;
     const char* const env = test_knob("TCGNN_SYNC");
     const int knob = env ? atoi(env) : 1;
     if (!knob) return false;
     if (knob >= 2 || mode == 5) return true;
-    return has_locality(plan) && windows_balanced(plan) && plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 10.0 * 1048576.0;
+    if (!(has_locality(plan) && windows_balanced(plan)) || pitch_bytes <= 128) return false;
+    return op == kSyncSpmm || plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 10.0 * 1048576.0;
 }
 static SyncArgs sync_args(const tcgnn_plan* plan, int pitch_bytes) {
     const tcgnn_plan::SyncTables& t = plan->sync;
@@ -1055,7 +1062,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                                                                      //  in contiguous order is 6 % faster - 1.70 against 1.79 ms per call - so only images beyond the Infinity Cache's reach)
                                                                                      (!d_val || x16_bytes > ((size_t)64 << 20))));
     // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round
-    if (!d_W && !a.big && sync_chosen(plan, pitch * 2, mode)) {
+    if (!d_W && !a.big && sync_chosen(plan, pitch * 2, mode, kSyncSpmm)) {
         KernelTimer timer(plan, stream, "spmm_sync_kernel");
         SpmmSyncArgs sa{a, sync_args(plan, pitch * 2)};
         auto wgs = [&](int nt) {   // workgroups per launch: what holds a slice (S windows per XCD, 4 wavefronts x MAXW windows per workgroup), at most what is resident
@@ -1145,7 +1152,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     // run of d_w slots
     // (the backward kernel beyond 96 columns owns its windows at ONE wavefront per SIMD - 256 registers do not hold two windows' accumulators, operands
     //  and per-row exponents - and loses more than the walk returns there: products shape, D = 128, 4.10 -> 6.24 ms; it stays per-window unless forced)
-    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan));
+    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), kSyncScores);
     const bool sync_one = bwd && nt > 6;   // (r06: ONE window per wavefront there - two wavefronts per SIMD, three trips per slice)
     {
         KernelTimer timer(plan, stream, synced ? "agnn_kernel (slice-synchronised)" : ((sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel"));
@@ -1749,7 +1756,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
     const bool blocked = ks <= 4 && plan->nbuckets > 0 && spmm_mode_of(plan) != 1 && (spmm_mode_of(plan) == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
     hipError_t e = hipSuccess;
-    if (ks <= 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan))) {
+    if (ks <= 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), kSyncScores)) {
         // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round, bit-identical scores
         plan->last_kernel.store("sddmm_kernel (slice-synchronised)", std::memory_order_relaxed);
         a.use_sync = 1;

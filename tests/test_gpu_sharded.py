@@ -279,6 +279,56 @@ def test_row_shard_on_the_xcd_sliced_and_xcd_affine_walks(D, monkeypatch):
     ops.close()
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_row_shard_on_the_slice_synchronised_walk(D, monkeypatch, capfd):
+    """r06: a rank's rectangular shard of a graph with communities (rows H .. 2H of 2H nodes, 16 communities, 90 % of the edges inside)
+    on the slice-synchronised range walk - its tables are built for shards too (the columns are global, the SDDMM's window rows sit at
+    row_offset inside X), so the automatic mode may take it there: forced (mode 5) against float64 gathers and the per-window walk;
+    the scores bit for bit."""
+    import tcgnn_capi as c
+    import tcgnn_shard as S
+    dev = torch.device("cuda:0")
+    H = 40_000
+    rp, col = graphs.community_graph(2 * H, 16, 50, 0.9, seed=13)
+    layout = S.ShardLayout([0, H, 2 * H])
+    lrp, lcol = S.local_csr(rp, col, layout, 1)
+    rows = len(lrp) - 1
+    monkeypatch.setenv("TCGNN_VERBOSE", "1")
+    ops = S.HipShardOps(lrp, lcol, layout, 1, dev)      # rank 1: row_off = H
+    assert "sync walk:" in capfd.readouterr().err
+    g = torch.Generator(device=dev).manual_seed(D)
+    X = torch.randn(layout.num_cols, D, device=dev, generator=g) / D ** 0.5
+    att = torch.randn(lcol.size, device=dev, generator=g)
+    tcol = torch.from_numpy(np.ascontiguousarray(lcol)).to(dev).long()
+    erow = torch.repeat_interleave(torch.arange(rows, device=dev), torch.from_numpy(np.diff(lrp)).to(dev).long())
+    Xn = X[tcol].double()
+    ref = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, Xn)
+    scale = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, Xn.abs()) + 1.0
+    refv = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, att.double()[:, None] * Xn)
+    scalev = torch.zeros(rows, D, dtype=torch.float64, device=dev).index_add_(0, erow, (att.double()[:, None] * Xn).abs()) + 1.0
+    Xr = X[ops.row_off + erow].double()
+    refe = (Xr * Xn).sum(1); scalee = (Xr * Xn).abs().sum(1) + 1.0
+    name = lambda: c.lib.tcgnn_plan_last_kernel(ops.plan).decode()
+    out = {}
+    try:
+        for mode in (1, 5):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            y = ops.spmm(X); k1 = name()
+            yv = ops.spmm_val(X, att); k2 = name()
+            ef = ops.sddmm(X); k3 = name()
+            out[mode] = (y, yv, ef, (k1, k2, k3))
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+    assert out[5][3] == ("spmm_sync_kernel", "spmm_sync_kernel", "sddmm_kernel (slice-synchronised)"), out[5][3]
+    for mode in (1, 5):
+        assert ((out[mode][0].double() - ref).abs() / scale).max().item() <= 2.0 ** -9
+        assert ((out[mode][1].double() - refv).abs() / scalev).max().item() <= 2.0 ** -9
+        assert ((out[mode][2].double() - refe).abs() / scalee).max().item() <= 2.0 ** -9
+    assert ((out[5][0] - out[1][0]).abs().double() / scale).max().item() <= 1e-5
+    assert torch.equal(out[5][2], out[1][2])
+    ops.close()
+
+
 def _rccl_worker(rank, world, port, out_dir):
     """World of ONE under backend "nccl" (= RCCL): every collective of the N-rank step executes - all_gather_into_tensor of the
     fp32 row blocks, the one-word int32 all_reduce(MAX), all_gather_into_tensor of the fp16 image slices into the strided view,
