@@ -576,7 +576,7 @@ def single_gpu(args):
         for shape, gen, d, ops in ((args.shape, second, D, every + ("gcn_epoch", "agnn_epoch")), (args.shape, "sbm", D, every + ("gcn_epoch", "agnn_epoch")),
                                    (args.shape, "rmat", D, every + ("gcn_epoch", "agnn_epoch")), *more,
                                    ("ogbn-products", "uniform", 128, every + ("gcn_epoch", "agnn_epoch")),
-                                   ("ogbn-products", "sbm", 128, every),
+                                   ("ogbn-products", "sbm", 128, every + ("gcn_epoch", "agnn_epoch")),   # (r06: config 4's model end to end on the graph with communities)
                                    ("ogbn-products", "rmat", 128, every)):
             try:
                 datasets.append(dataset_legs(shape, gen.split("+")[0], d, ops, args.seed, reorder=gen.endswith("+reorder")))
@@ -991,6 +991,7 @@ def compact_line(out, limit=LINE_LIMIT):
             # r06: the community graph at ogbn-products size - communities of 12.5 MB, three times an XCD's L2: the
             # slice-synchronised range walk (spmm_sync_kernel and its SDDMM / fused-forward forms)
             summary += [("products_sbm_%s_ms" % op, _leg(row.get(op))) for op in ("spmm", "sddmm", "spmm_val", "agnn_fused_fwd", "agnn_fused_bwd")]
+            summary += [("products_sbm_agnn_h128_ms_per_epoch", row.get("agnn_ms_per_epoch")), ("products_sbm_gcn_h128_ms_per_epoch", row.get("gcn_ms_per_epoch"))]
             summary += [("products_sbm_spmm_kernel", clip(_leg(row.get("spmm"), "kernel"), 40)), ("products_sbm_spmm_traffic", _leg(row.get("spmm"), "traffic")),
                         ("products_sbm_sddmm_traffic", _leg(row.get("sddmm"), "traffic")), ("products_sbm_spmm_frac", _leg(row.get("spmm"), "hbm_frac")),
                         ("products_sbm_sddmm_frac", _leg(row.get("sddmm"), "hbm_frac"))]
