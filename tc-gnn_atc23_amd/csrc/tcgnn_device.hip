@@ -553,10 +553,12 @@ static bool ranges_fit_l2(const tcgnn_plan* plan, size_t x16_bytes) {
 // (more wavefronts thrash the L2 harder) - level with range-major's 1.45-1.48, so not kept either.
 // TCGNN_AGNN_SLICED (read per call: tests switch it): 0 per-window only, 1 the rule above, 2 sliced whenever possible, 16 two rounds.
 static constexpr size_t kAgnnSliceBytes = (size_t)4 << 20;
-// (r06) the sliced walk takes the windows in their own order, rotated per XCD (AgnnArgs::rot), unless hub windows must start first
+// (r06) on a graph with locality the sliced walk takes the windows in their own order, rotated per XCD (AgnnArgs::rot: sbm_reddit, forced
+// sliced, 1.96 / 2.50 -> 1.59 / 1.63 ms) - which only a forced walk meets: the automatic rule keeps such graphs per-window.  Without locality
+// the plan's order stays (uniform graph: 1.61 / 1.63 against 1.62 / 1.67 rotated).  TCGNN_AGNN_ROT=0|1 overrides.
 static int agnn_rot(const tcgnn_plan* plan) {
     const char* const env = test_knob("TCGNN_AGNN_ROT");
-    return (env ? atoi(env) : 1) && windows_balanced(plan) ? 1 : 0;
+    return (env ? atoi(env) != 0 : plan->near_frac > 0.2) && windows_balanced(plan) ? 1 : 0;
 }
 enum { kAgnnPerWindow = 0, kAgnnSliced = 1, kAgnnRangeMajor = 2 };
 static int agnn_walk(const tcgnn_plan* plan, int32_t D, bool bwd, int* nslices_out) {

@@ -1008,8 +1008,9 @@ def test_two_plans_of_one_process_walk_differently(dev, T):
         T.clear_plan_cache()
 
 
+@pytest.mark.parametrize("rot", ["0", "1"])   # (r06: windows in the plan's order / in their own order, rotated per XCD - AgnnArgs::rot, the default on graphs with locality)
 @pytest.mark.parametrize("D", [16, 41, 64, 96, 128])   # (128: what the backward pass takes on the Reddit shape since r03; 96: the old row layout)
-def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatch):
+def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, rot, monkeypatch):
     """r03: the XCD-sliced walk of the fused kernel (workgroup b gathers only rows of column slice b % 8, so an XCD's L2 holds the
     slice it is asked for; a wavefront = one window's tiles inside the slice; the slices' addends of Y summed in slice order by
     agnn_slice_sum_kernel).  Automatic for images of 6 - 16 MB, forced here (TCGNN_AGNN_SLICED = 2: eight slices, 16: two rounds
@@ -1020,6 +1021,7 @@ def test_fused_agnn_xcd_sliced_walk_equals_per_window_walk(dev, T, D, monkeypatc
     (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
     meta = (trp, tcol, tbp, te2c, te2r)
     assert T.plan_info(*meta)["column_buckets"] % 16 == 0
+    monkeypatch.setenv("TCGNN_AGNN_ROT", rot)
     rng = np.random.default_rng(D + 9)
     H = (rng.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
     dY = rng.standard_normal((n, D)).astype(np.float32)
