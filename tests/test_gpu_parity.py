@@ -1295,6 +1295,40 @@ def test_epoch_captured_in_a_hip_graph_trains_like_the_eager_loop(dev, T):
         assert abs(long_g["final_loss"] - long_e["final_loss"]) <= 0.5 * max(long_e["final_loss"], short["final_loss"]), (model, long_g, long_e)
 
 
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_training_on_the_slice_synchronised_walk_follows_the_per_window_walk(dev, T, hip_graph):
+    """r06: whole GCN and AGNN epochs (hidden 128: forward, forward_AGNN / the fused pair and their backward passes, autograd, Adam) with
+    every aggregation on the slice-synchronised walk (mode 5: one launch per slice round, several launches per operator call) against
+    the same epochs on the per-window walk - eager, and captured once in a HIP graph and replayed (every launch of a call must be
+    capturable).  Both runs seed torch alike, so they draw the same dropout masks; the bar is loose all the same: summation orders
+    differ between the walks."""
+    import tcgnn_capi as c
+    import tcgnn_harness as H
+    rp, col = graphs.community_graph(40003, 16, 60, 0.9, seed=31)
+    _, (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
+    meta = (trp, tcol, tbp, te2c, te2r)
+    n = len(rp) - 1
+    x = torch.randn(n, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 0.1
+    y = torch.ones(n, dtype=torch.long, device=dev)
+    out = {}
+    try:
+        for mode in (1, 5):
+            c.check(c.lib.tcgnn_set_spmm_mode(mode), "tcgnn_set_spmm_mode")
+            T.clear_plan_cache()
+            for model in ("gcn", "agnn"):
+                torch.manual_seed(7)
+                out[(mode, model)] = H.time_training(model, meta, x, y, 48, 128, 7, 2, epochs=6, seed=0, warmup=2, hip_graph=hip_graph)
+            T.forward(torch.randn(n, 128, device=dev), *meta)
+            assert (T.last_kernel(*meta) == "spmm_sync_kernel") == (mode == 5)
+    finally:
+        c.lib.tcgnn_set_spmm_mode(0)
+        T.clear_plan_cache()
+    for model in ("gcn", "agnn"):
+        a, b = out[(1, model)]["final_loss"], out[(5, model)]["final_loss"]
+        assert np.isfinite(a) and np.isfinite(b), (model, a, b)
+        assert abs(a - b) <= 0.05 * max(abs(a), 1e-3) + 1e-4, (model, a, b)
+
+
 @pytest.mark.parametrize("shape", [(40000, 64, 41), (70001, 96, 16), (33000, 602, 64), (40000, 16, 64)])
 def test_tall_dense_updates_match_a_float64_product(dev, shape):
     """The layers' tall products (tcgnn_layers.tall_mm / tall_nt_mm / tall_tn_mm) against float64: fp32 GEMM accuracy, 1e-5 of
