@@ -622,14 +622,15 @@ def test_locality_statistic_of_the_numbering(dev, T, capfd, monkeypatch):
     assert 8 <= seen["uniform"] <= 20 and seen["sbm"] >= 75, seen
 
 
+@pytest.mark.parametrize("graph", ["uniform", "communities"])   # (r06: a graph with communities - where the walk's window order decides whether it stays in step)
 @pytest.mark.parametrize("D", [16, 64, 128])
-def test_sddmm_range_major_walk_with_xcd_affinity_gives_the_same_scores(dev, T, D, monkeypatch):
+def test_sddmm_range_major_walk_with_xcd_affinity_gives_the_same_scores(dev, T, D, graph, monkeypatch):
     """r03: the range-major SDDMM with XCD affinity (workgroup b takes the column ranges b % 8, b % 8 + 8, ... only, so an XCD's
     L2 is asked for an eighth of the image).  Every edge lies in exactly one range: the scores are bit for bit those of the
     per-window walk and of the range-major walk without affinity.  Forced here with small ranges (TCGNN_RANGE_KB) on a graph the
     oracle can handle, N % 16 != 0, so that there are 8, 16 and more ranges."""
     import tcgnn_capi as c
-    rp, col = graphs.uniform_graph(70003, 80, seed=23)
+    rp, col = graphs.uniform_graph(70003, 80, seed=23) if graph == "uniform" else graphs.community_graph(70003, 50, 80, 0.3, seed=23)
     n = len(rp) - 1
     (bp, e2c, e2r), (trp, tcol, tbp, te2c, te2r) = meta_for(dev, rp, col)
     meta = (trp, tcol, tbp, te2c, te2r)
@@ -646,9 +647,11 @@ def test_sddmm_range_major_walk_with_xcd_affinity_gives_the_same_scores(dev, T, 
         image_kb = (n + 1) * max(32, 1 << int(np.ceil(np.log2(2 * ((D + 15) // 16 * 16))))) // 1024
         for xcd in ("0", "1"):
             for parts in (8, 16, 64):
-                monkeypatch.setenv("TCGNN_SDDMM_XCD", "2" if xcd == "1" else "0")
-                monkeypatch.setenv("TCGNN_RANGE_KB", str(max(1, image_kb // parts)))
-                out[(xcd, parts)] = T.forward_ef(tX, *meta)[0]
+                for ident in ("1", "0"):   # (r06: items in the graph's own order - the default - and through the plan's XCD-contiguous order)
+                    monkeypatch.setenv("TCGNN_SDDMM_XCD", "2" if xcd == "1" else "0")
+                    monkeypatch.setenv("TCGNN_RM_IDENT", ident)
+                    monkeypatch.setenv("TCGNN_RANGE_KB", str(max(1, image_kb // parts)))
+                    out[(xcd, parts, ident)] = T.forward_ef(tX, *meta)[0]
     finally:
         c.lib.tcgnn_set_spmm_mode(0)
     base = out["per-window"]
