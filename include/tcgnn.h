@@ -192,8 +192,7 @@ int tcgnn_plan_get_info(const tcgnn_plan* plan, tcgnn_plan_info* info);
  * LDS-resident column-range kernel (binary SpMM only; builds its cell stream on first use if the
  * plan was created without one), 4 = the single-launch fp32-MFMA kernel small graphs take automatically
  * (no staging pass; binary SpMM only), 5 = the slice-synchronised range walk (r06: graphs whose communities exceed an XCD's L2 -
- * taken automatically there - beyond 64 columns: the SpMM whenever the plan's tables exist, SDDMM and the fused AGNN pair where a
- * slice's hot column buckets span more than ~10 MB of image; forced, it runs wherever the plan built its tables and falls back to the
+ * taken automatically there - from 64 columns, sparse windows, by operator and hot span: DESIGN.md 4.4; forced, it runs wherever the plan built its tables and falls back to the
  * gather walks elsewhere; SDDMM and the fused AGNN pair follow the same switch).  Process-wide; the environment variable TCGNN_SPMM_MODE sets the initial value. */
 int tcgnn_set_spmm_mode(int32_t mode);
 /* The same switch for ONE plan: mode 0 .. 5 as above, -1 = follow the process-wide value (the default).  Two plans of one process may

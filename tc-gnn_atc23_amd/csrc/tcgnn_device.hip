@@ -401,8 +401,8 @@ static hipError_t launch_blocked_any(bool val, int nt, const SpmmBlockedArgs& ar
 // spill 34-44 words at 128 columns), so that twelve wavefronts fit a CU instead of eight - 768 windows per XCD in flight: the slice (kSyncSlice).
 // (r06, later: the single-buffer kernels walk their runs as ONE pipeline - TileWalker::walk_list - whose three list cursors do not fit the
 //  168 registers of twelve wavefronts at 7-8 tiles of width: eight wavefronts of 3 windows, 256 registers - 768 windows per XCD again)
-static constexpr int sync_nbuf(int nt, bool val) { return nt <= 4 ? 2 : 1; }
-static constexpr int sync_maxw(int nt, bool val) { return nt <= 4 ? 4 : 2; }
+static constexpr int sync_nbuf(int nt, bool val) { return nt <= 2 ? 2 : 1; }
+static constexpr int sync_maxw(int nt, bool val) { return 2; }
 static constexpr int sync_wgs_per_cu(int nt, bool val) {
     const int lds_wg = 4 * (sync_nbuf(nt, val) * nt * 1024 + kPadBytes + (val ? 2048 : 0) + (sync_nbuf(nt, val) == 1 ? 2048 : 0)) + 4096;
     const int by_lds = (160 * 1024) / lds_wg, by_regs = nt <= 4 ? 4 : 2;
@@ -749,22 +749,43 @@ static int build_sync_tables(tcgnn_plan* p, hipStream_t stream) {
     return TCGNN_OK;
 }
 // When the walk is taken (automatic mode; TCGNN_SYNC=0 never, 2 whenever the tables exist; mode 5 forces it).  Measured on the ogbn-products
-// shape with 25 / 50 / 100 / 200 communities (25 / 12.5 / 6.3 / 3.1 MB of image each at D = 128; tools/exp_r06d.py, kernel ms, per-window -> this walk):
-//   SpMM  D = 128   3.95 -> 3.15   3.65 -> 2.66   3.20 -> 2.52   3.02 -> 2.46     it wins at every size: beyond 64 columns whenever the tables exist
-//   SDDMM D = 128   4.00 -> 3.49   3.43 -> 2.89   2.56 -> 2.64   2.30 -> 2.51     only where the hot span of a slice (avg_k buckets) exceeds ~10 MB
-//   SpMM  D = 64    1.77 -> 2.27   1.49 -> 2.16   1.43 -> 2.09   1.38 -> 2.02     never: up to 64 columns the per-window walk's rows are one line each
-//   SDDMM D = 64    1.84 -> 1.95   1.71 -> 1.85   1.67 -> 1.77   1.64 -> 1.62     and a community's image is half the size
-// (the fused pair follows the SDDMM's rule: measured at 50 communities only, 4.15 / 4.03 -> 3.62 / 3.83).
-enum { kSyncSpmm = 0, kSyncScores = 1 };
+// shape with 25 / 50 / 100 / 200 communities (25 / 12.5 / 6.3 / 3.1 MB of image each at D = 128, half that at 64; tools/exp_r06d.py, kernel ms,
+// per-window -> this walk):
+//                      25             50             100            200
+//   SpMM       D = 128   3.94 -> 3.13   3.64 -> 2.63   3.14 -> 2.47   3.02 -> 2.46     always
+//   edge-valued          4.22 -> 3.70   3.95 -> 3.19   3.79 -> 2.98                    always
+//   SDDMM                3.98 -> 3.39   3.39 -> 2.83   2.53 -> 2.54   2.30 -> 2.51     where a slice's hot span (avg_k buckets) exceeds ~10 MB of image
+//   fused fwd            4.39 -> 4.41   4.17 -> 3.61   4.05 -> 3.29                    where it stays below ~20 MB (beyond, the two windows a
+//   fused bwd            4.29 -> 4.42   4.03 -> 3.83   3.88 -> 3.57                    wavefront owns walk more phases than its L2 share covers)
+//   SpMM       D = 64    1.77 -> 1.55   1.49 -> 1.49   1.42 -> 1.43                    beyond ~10 MB of hot span
+//   edge-valued          2.15 -> 2.09   2.13 -> 2.02   2.07 -> 1.93                    always
+//   SDDMM                1.84 -> 1.88   1.69 -> 1.77   1.65 -> 1.68                    never
+//   fused fwd            2.29 -> 2.16   2.29 -> 2.03   2.24 -> 1.94                    always
+//   fused bwd            2.24 -> 2.35   2.22 -> 2.24   2.18 -> 2.17                    never
+// and at 48 columns (three tiles of width) every operator loses 5 - 10 %: the walk starts at 64.
+// All of this holds for SPARSE windows - 25 wide blocks per window on that shape: the per-window walk splits a window over four wavefronts,
+// and at ~6 tiles each its run starts and four-way reduction weigh as much as the gathers.  On the Reddit shape with 50 communities (141
+// wide blocks per window, communities of 1.2 MB) the per-window walk is the better kernel for every operator (D = 128: SpMM 1.04 against
+// 1.13 ms, SDDMM 1.14 / 1.28, fused 1.37 / 1.51 and 1.36 / 1.81; D = 64: edge-valued 0.80 / 0.97): the walk is only taken up to 64 wide
+// blocks per window.
+enum { kSyncSpmm = 0, kSyncVal = 1, kSyncSddmm = 2, kSyncFusedFwd = 3, kSyncFusedBwd = 4 };
 static constexpr size_t kSyncPhaseBytes = (size_t)3 << 20;   // image bytes of one phase (products shape, D = 128: 3.01 / 2.77 / 2.72 ms at 1 / 2 / 3 MB)
-static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode, int op) {
+static bool sync_chosen(const tcgnn_plan* plan, int pitch_bytes, int mode, int op, int nt) {
     if (!plan->sync.ok || (mode != 0 && mode != 5)) return false;
     const char* const env = test_knob("TCGNN_SYNC");
     const int knob = env ? atoi(env) : 1;
     if (!knob) return false;
     if (knob >= 2 || mode == 5) return true;
-    if (!(has_locality(plan) && windows_balanced(plan)) || pitch_bytes <= 128) return false;
-    return op == kSyncSpmm || plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) > 10.0 * 1048576.0;
+    if (!(has_locality(plan) && windows_balanced(plan)) || nt < 4 || plan->total_wb > (int64_t)64 * plan->nw_eff) return false;
+    const double span_mb = plan->sync.avg_k * (double)((size_t)pitch_bytes << plan->sync.fb_shift) / 1048576.0;
+    const bool wide = nt > 4;
+    switch (op) {
+        case kSyncSpmm: return wide || span_mb > 10.0;
+        case kSyncVal: return true;
+        case kSyncSddmm: return wide && span_mb > 10.0;
+        case kSyncFusedFwd: return !wide || span_mb < 20.0;
+        default: return wide && span_mb < 20.0;   // kSyncFusedBwd
+    }
 }
 static SyncArgs sync_args(const tcgnn_plan* plan, int pitch_bytes) {
     const tcgnn_plan::SyncTables& t = plan->sync;
@@ -1064,7 +1085,7 @@ static int run_spmm(const tcgnn_plan* plan, const float* d_X, const float* d_val
                                                                                      //  in contiguous order is 6 % faster - 1.70 against 1.79 ms per call - so only images beyond the Infinity Cache's reach)
                                                                                      (!d_val || x16_bytes > ((size_t)64 << 20))));
     // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round
-    if (!d_W && !a.big && sync_chosen(plan, pitch * 2, mode, kSyncSpmm)) {
+    if (!d_W && !a.big && sync_chosen(plan, pitch * 2, mode, d_val ? kSyncVal : kSyncSpmm, dpad / 16)) {
         KernelTimer timer(plan, stream, "spmm_sync_kernel");
         SpmmSyncArgs sa{a, sync_args(plan, pitch * 2)};
         auto wgs = [&](int nt) {   // workgroups per launch: what holds a slice (S windows per XCD, 4 wavefronts x MAXW windows per workgroup), at most what is resident
@@ -1154,7 +1175,7 @@ static int run_agnn(const tcgnn_plan* plan, const float* d_X, const float* d_w, 
     // run of d_w slots
     // (the backward kernel beyond 96 columns owns its windows at ONE wavefront per SIMD - 256 registers do not hold two windows' accumulators, operands
     //  and per-row exponents - and loses more than the walk returns there: products shape, D = 128, 4.10 -> 6.24 ms; it stays per-window unless forced)
-    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), kSyncScores);
+    const bool synced = plan->waves == 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), bwd ? kSyncFusedBwd : kSyncFusedFwd, nt);
     const bool sync_one = bwd && nt > 6;   // (r06: ONE window per wavefront there - two wavefronts per SIMD, three trips per slice)
     {
         KernelTimer timer(plan, stream, synced ? "agnn_kernel (slice-synchronised)" : ((sliced && !blocked) ? "agnn_kernel (XCD-sliced) + agnn_slice_sum_kernel" : "agnn_kernel"));
@@ -1758,7 +1779,7 @@ int tcgnn_sddmm(const tcgnn_plan* plan, const float* d_X, float* d_ef, int32_t D
     // D=64 1.74 -> 1.66, D=128 3.37 -> 3.26.  No accumulators live across ranges, so ranges are 4x the SpMM's.
     const bool blocked = ks <= 4 && plan->nbuckets > 0 && spmm_mode_of(plan) != 1 && (spmm_mode_of(plan) == 2 || (x16_bytes > kBlockedMinBytes && windows_balanced(plan) && ranges_fit_l2(plan, x16_bytes) && !has_locality(plan)));
     hipError_t e = hipSuccess;
-    if (ks <= 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), kSyncScores)) {
+    if (ks <= 4 && !a.big && sync_chosen(plan, pitch * 2, spmm_mode_of(plan), kSyncSddmm, dpad / 16)) {
         // slice-synchronised range walk (r06, tcgnn_sync_walk.inc): communities larger than an XCD's L2; one launch per slice round, bit-identical scores
         plan->last_kernel.store("sddmm_kernel (slice-synchronised)", std::memory_order_relaxed);
         a.use_sync = 1;

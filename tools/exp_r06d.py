@@ -23,6 +23,7 @@ for blocks in [int(x) for x in os.environ.get("BLOCKS", "25,50,100,200").split("
         t = np.array(TCGNN.kernel_timing(*meta)).reshape(reps, -1).sum(1)
         TCGNN.kernel_timing(*meta, max_calls=0)
         return float(np.median(t))
+    att = torch.randn(1, E, device=dev, generator=g); w = torch.tensor([0.9], device=dev)
     for D in [int(x) for x in os.environ.get("DIMS", "128").split(",")]:
         X = torch.randn(n, D, device=dev, generator=g) / D ** 0.5
         res = []
@@ -30,7 +31,11 @@ for blocks in [int(x) for x in os.environ.get("BLOCKS", "25,50,100,200").split("
             c.lib.tcgnn_set_spmm_mode(mode)
             t1 = timed(lambda: TCGNN.forward(X, *meta)); k1 = TCGNN.last_kernel(*meta)
             t2 = timed(lambda: TCGNN.forward_ef(X, *meta)); k2 = TCGNN.last_kernel(*meta)
-            res.append("mode %d spmm %.3f (%s) sddmm %.3f (%s)" % (mode, t1, k1.replace("_kernel", ""), t2, k2.replace("_kernel", "")))
+            t3 = timed(lambda: TCGNN.forward_AGNN(X, rp, col, att, bp, e2c, e2r))
+            t4 = timed(lambda: TCGNN.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r))
+            _, eff, efm = TCGNN.agnn_fused_forward(X, rp, col, w, bp, e2c, e2r)
+            t5 = timed(lambda: TCGNN.agnn_fused_backward(X, rp, col, w, eff, efm, bp, e2c, e2r))
+            res.append("mode %d spmm %.3f (%s) sddmm %.3f (%s) val %.3f fused %.3f / %.3f" % (mode, t1, k1.replace("_kernel", ""), t2, k2.replace("_kernel", ""), t3, t4, t5))
         c.lib.tcgnn_set_spmm_mode(0)
         print("blocks %3d D=%d: " % (blocks, D) + " | ".join(res), flush=True)
         del X
